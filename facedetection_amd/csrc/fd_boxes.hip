@@ -1,0 +1,921 @@
+// Box-stage kernels for gfx950: delta decode / clip / min-size filter, stable segmented
+// radix sort, bitmask IoU NMS, RPN proposal assembly, ROI max pooling and the detector
+// tail.  All of this is integer / latency / HBM-bound work: 64-wide wave ballots for
+// ranking and counting, LDS for the per-block digit tables and the suppression bitmap,
+// no matrix cores.
+//
+// Floating-point contraction is off for the whole file: the IoU and decode arithmetic
+// has to round exactly where NumPy rounds (one rounding per +, -, *, /), so no a*b+c may
+// be fused.  (The build also passes -ffp-contract=off.)
+#include "fd_boxes.h"
+
+#include <cfloat>
+#include <cmath>
+#include <cstring>
+
+#pragma clang fp contract(off)
+
+namespace fd {
+
+// ---------------------------------------------------------------------------------
+// Sort keys: ascending key order == descending score order.
+// ---------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t desc_key(float s) {
+    if (s == 0.0f) s = 0.0f;   // -0.0 and +0.0 compare equal and must tie
+    uint32_t u = __float_as_uint(s);
+    uint32_t asc = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+    return ~asc;
+}
+__device__ __forceinline__ uint64_t desc_key(double s) {
+    if (s == 0.0) s = 0.0;
+    uint64_t u = (uint64_t)__double_as_longlong(s);
+    uint64_t asc = (u & 0x8000000000000000ull) ? ~u : (u | 0x8000000000000000ull);
+    return ~asc;
+}
+constexpr uint32_t KEY_INVALID32 = 0xFFFFFFFFu;   // sorts behind every real score
+
+// ---------------------------------------------------------------------------------
+// Stable segmented LSD radix sort, 8-bit digits.
+// One tile = 256 threads x 8 rounds; in round r thread t owns element tile*2048 + r*256 + t,
+// so (round, wave, lane) order is element order and ranks can be taken with wave ballots.
+// ---------------------------------------------------------------------------------
+constexpr int SORT_THREADS = 256;
+constexpr int SORT_ROUNDS = 8;
+constexpr int SORT_TILE = SORT_THREADS * SORT_ROUNDS;
+
+template <typename K>
+__global__ __launch_bounds__(SORT_THREADS) void sort_hist_kernel(const K* __restrict__ keys, int n, int shift,
+                                                                uint32_t* __restrict__ hist, int nblk) {
+    __shared__ uint32_t h[256];
+    const int tid = threadIdx.x, blk = blockIdx.x, seg = blockIdx.y;
+    h[tid] = 0;
+    __syncthreads();
+    const K* k = keys + (size_t)seg * n;
+    const int base = blk * SORT_TILE;
+#pragma unroll
+    for (int r = 0; r < SORT_ROUNDS; ++r) {
+        const int i = base + r * SORT_THREADS + tid;
+        if (i < n) atomicAdd(&h[(uint32_t)(k[i] >> shift) & 255u], 1u);
+    }
+    __syncthreads();
+    hist[((size_t)seg * 256 + tid) * nblk + blk] = h[tid];
+}
+
+template <typename K>
+__global__ __launch_bounds__(SORT_THREADS) void sort_scatter_kernel(const K* __restrict__ keys_in,
+                                                                   const uint32_t* __restrict__ vals_in,
+                                                                   K* __restrict__ keys_out,
+                                                                   uint32_t* __restrict__ vals_out, int n, int shift,
+                                                                   const uint32_t* __restrict__ hist, int nblk) {
+    __shared__ uint32_t digit_base[256];
+    __shared__ uint32_t wave_cnt[4][256];
+    __shared__ uint32_t scan[256];
+    const int tid = threadIdx.x, blk = blockIdx.x, seg = blockIdx.y;
+    const int lane = tid & 63, wave = tid >> 6;
+
+    // Where does this tile's first element of digit `tid` go?  Elements of smaller digits
+    // (all tiles) come first, then the same digit in earlier tiles.
+    uint32_t total = 0, before = 0;
+    const uint32_t* row = hist + ((size_t)seg * 256 + tid) * nblk;
+    for (int b = 0; b < nblk; ++b) {
+        const uint32_t c = row[b];
+        if (b < blk) before += c;
+        total += c;
+    }
+    scan[tid] = total;
+    __syncthreads();
+    for (int off = 1; off < 256; off <<= 1) {   // inclusive Hillis-Steele scan over the 256 digits
+        uint32_t v = (tid >= off) ? scan[tid - off] : 0u;
+        __syncthreads();
+        scan[tid] += v;
+        __syncthreads();
+    }
+    digit_base[tid] = scan[tid] - total + before;
+    wave_cnt[0][tid] = wave_cnt[1][tid] = wave_cnt[2][tid] = wave_cnt[3][tid] = 0;
+    __syncthreads();
+
+    const size_t seg_off = (size_t)seg * n;
+    const int base = blk * SORT_TILE;
+    const uint64_t lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    for (int r = 0; r < SORT_ROUNDS; ++r) {
+        const int i = base + r * SORT_THREADS + tid;
+        const bool valid = i < n;
+        K key = 0;
+        uint32_t val = 0, d = 0;
+        if (valid) {
+            key = keys_in[seg_off + i];
+            val = vals_in[seg_off + i];
+            d = (uint32_t)(key >> shift) & 255u;
+        }
+        // lanes of this wave holding the same digit
+        uint64_t peers = __ballot(valid);
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+            const uint64_t m = __ballot(valid && ((d >> b) & 1u));
+            peers &= ((d >> b) & 1u) ? m : ~m;
+        }
+        const uint32_t rank = __popcll(peers & lt_mask);
+        if (valid && rank == 0) wave_cnt[wave][d] = __popcll(peers);
+        __syncthreads();
+        if (valid) {
+            uint32_t pos = digit_base[d] + rank;
+            for (int w = 0; w < wave; ++w) pos += wave_cnt[w][d];
+            keys_out[seg_off + pos] = key;
+            vals_out[seg_off + pos] = val;
+        }
+        __syncthreads();
+        digit_base[tid] += wave_cnt[0][tid] + wave_cnt[1][tid] + wave_cnt[2][tid] + wave_cnt[3][tid];
+        wave_cnt[0][tid] = wave_cnt[1][tid] = wave_cnt[2][tid] = wave_cnt[3][tid] = 0;
+        __syncthreads();
+    }
+}
+
+template <typename K>
+static int sort_pairs(fd_ctx* ctx, K* keys_a, uint32_t* vals_a, K* keys_b, uint32_t* vals_b, int n, int nseg,
+                      hipStream_t stream) {
+    if (n <= 0 || nseg <= 0) return FD_OK;
+    const int nblk = ceil_div(n, SORT_TILE);
+    uint32_t* hist = nullptr;
+    FD_TRY(scratch_as(ctx, SLOT_SORT_HIST, (size_t)nseg * 256 * nblk, &hist));
+    dim3 grid(nblk, nseg);
+    K* src_k = keys_a;
+    uint32_t* src_v = vals_a;
+    K* dst_k = keys_b;
+    uint32_t* dst_v = vals_b;
+    for (int shift = 0; shift < (int)sizeof(K) * 8; shift += 8) {
+        hipLaunchKernelGGL(sort_hist_kernel<K>, grid, dim3(SORT_THREADS), 0, stream, src_k, n, shift, hist, nblk);
+        FD_LAUNCH_CHECK();
+        hipLaunchKernelGGL(sort_scatter_kernel<K>, grid, dim3(SORT_THREADS), 0, stream, src_k, src_v, dst_k, dst_v, n,
+                           shift, hist, nblk);
+        FD_LAUNCH_CHECK();
+        K* tk = src_k; src_k = dst_k; dst_k = tk;
+        uint32_t* tv = src_v; src_v = dst_v; dst_v = tv;
+    }
+    return FD_OK;   // an even number of passes: the result is back in (keys_a, vals_a)
+}
+
+int sort_pairs_u32(fd_ctx* ctx, uint32_t* ka, uint32_t* va, uint32_t* kb, uint32_t* vb, int n, int nseg,
+                   hipStream_t stream) {
+    return sort_pairs<uint32_t>(ctx, ka, va, kb, vb, n, nseg, stream);
+}
+int sort_pairs_u64(fd_ctx* ctx, uint64_t* ka, uint32_t* va, uint64_t* kb, uint32_t* vb, int n, int nseg,
+                   hipStream_t stream) {
+    return sort_pairs<uint64_t>(ctx, ka, va, kb, vb, n, nseg, stream);
+}
+
+// ---------------------------------------------------------------------------------
+// Bitmask NMS.
+// mask[seg][i][w] bit b == 1  <=>  candidate j = 64 w + b (j > i) is suppressed by i,
+// i.e. NOT (iou(i, j) <= thresh), with the reference's arithmetic:
+//   area = (x2 - x1 + 1) * (y2 - y1 + 1)
+//   iw = max(0, min(x2i, x2j) - max(x1i, x1j) + 1), ih likewise, inter = iw * ih
+//   iou = inter / (area_i + area_j - inter)
+// Only the upper triangle (w >= i / 64) is written and read.
+// ---------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(64) void nms_mask_kernel(const T* __restrict__ boxes, const int32_t* __restrict__ counters,
+                                                      int cap, int words, T thresh, uint64_t* __restrict__ mask) {
+    const int col = blockIdx.x, rowc = blockIdx.y, seg = blockIdx.z;
+    if (col < rowc) return;
+    const int n = counters[seg * CNT_STRIDE + CNT_CAND];
+    if (rowc * 64 >= n || col * 64 >= n) return;
+    __shared__ T cb[64][5];
+    const int t = threadIdx.x;
+    const T* segb = boxes + (size_t)seg * cap * 4;
+    {
+        const int j = col * 64 + t;
+        T x1 = 0, y1 = 0, x2 = 0, y2 = 0;
+        if (j < n) {
+            x1 = segb[(size_t)j * 4 + 0];
+            y1 = segb[(size_t)j * 4 + 1];
+            x2 = segb[(size_t)j * 4 + 2];
+            y2 = segb[(size_t)j * 4 + 3];
+        }
+        cb[t][0] = x1; cb[t][1] = y1; cb[t][2] = x2; cb[t][3] = y2;
+        cb[t][4] = (x2 - x1 + T(1)) * (y2 - y1 + T(1));
+    }
+    __syncthreads();
+    const int i = rowc * 64 + t;
+    if (i >= n) return;
+    const T x1 = segb[(size_t)i * 4 + 0], y1 = segb[(size_t)i * 4 + 1];
+    const T x2 = segb[(size_t)i * 4 + 2], y2 = segb[(size_t)i * 4 + 3];
+    const T area = (x2 - x1 + T(1)) * (y2 - y1 + T(1));
+    const int jn = min(64, n - col * 64);
+    const int j0 = (col == rowc) ? t + 1 : 0;
+    uint64_t bits = 0;
+    for (int j = j0; j < jn; ++j) {
+        const T xx1 = (x1 > cb[j][0]) ? x1 : cb[j][0];
+        const T yy1 = (y1 > cb[j][1]) ? y1 : cb[j][1];
+        const T xx2 = (x2 < cb[j][2]) ? x2 : cb[j][2];
+        const T yy2 = (y2 < cb[j][3]) ? y2 : cb[j][3];
+        const T dw = xx2 - xx1 + T(1), dh = yy2 - yy1 + T(1);
+        const T iw = (dw > T(0)) ? dw : T(0);
+        const T ih = (dh > T(0)) ? dh : T(0);
+        const T inter = iw * ih;
+        const T iou = inter / (area + cb[j][4] - inter);
+        if (!(iou <= thresh)) bits |= 1ull << j;
+    }
+    mask[((size_t)seg * cap + i) * words + col] = bits;
+}
+
+__device__ __forceinline__ uint64_t wave_uniform_u64(uint64_t v) {
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v);
+    const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+    return ((uint64_t)hi << 32) | lo;
+}
+
+// One workgroup per image walks the candidates in chunks of 64.  Wave 0 resolves the
+// chunk against its own diagonal mask words; then every thread ORs the rows of the kept
+// boxes into its share of the `removed` bitmap (LDS).
+constexpr int REDUCE_THREADS = 1024;
+__global__ __launch_bounds__(REDUCE_THREADS) void nms_reduce_kernel(const uint64_t* __restrict__ mask,
+                                                                   int32_t* __restrict__ counters, int cap, int words,
+                                                                   int max_keep, int32_t* __restrict__ keep) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    uint64_t* removed = reinterpret_cast<uint64_t*>(smem_raw);          // [words]
+    uint64_t* s_kept = removed + words;                                  // [1]
+    int* s_count = reinterpret_cast<int*>(s_kept + 1);                   // [1]
+    const int seg = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+    const int n = counters[seg * CNT_STRIDE + CNT_CAND];
+    const int W = (n + 63) >> 6;
+    const uint64_t* segm = mask + (size_t)seg * cap * words;
+    int32_t* segk = keep + (size_t)seg * cap;
+    for (int w = tid; w < W; w += REDUCE_THREADS) removed[w] = 0;
+    if (tid == 0) { *s_count = 0; *s_kept = 0; }
+    __syncthreads();
+    for (int c = 0; c < W; ++c) {
+        if (tid < 64) {
+            const int i = c * 64 + lane;
+            const uint64_t diag = (i < n) ? segm[(size_t)i * words + c] : 0ull;
+            const uint32_t dlo = (uint32_t)diag, dhi = (uint32_t)(diag >> 32);
+            uint64_t rem = wave_uniform_u64(removed[c]);
+            const int left = n - c * 64;
+            if (left < 64) rem |= ~0ull << left;
+            uint64_t kept = 0;
+#pragma unroll
+            for (int b = 0; b < 64; ++b) {
+                if (!((rem >> b) & 1ull)) {
+                    kept |= 1ull << b;
+                    const uint32_t lo = __builtin_amdgcn_readlane(dlo, b);
+                    const uint32_t hi = __builtin_amdgcn_readlane(dhi, b);
+                    rem |= ((uint64_t)hi << 32) | lo;
+                }
+            }
+            const int count = *s_count;
+            if ((kept >> lane) & 1ull) {
+                const uint64_t below = (lane == 0) ? 0ull : (kept & (~0ull >> (64 - lane)));
+                const int pos = count + __popcll(below);
+                if (max_keep <= 0 || pos < max_keep) segk[pos] = i;
+            }
+            if (lane == 0) {
+                *s_kept = kept;
+                *s_count = count + __popcll(kept);
+            }
+        }
+        __syncthreads();
+        const uint64_t kept = *s_kept;
+        const int count = *s_count;
+        if (max_keep > 0 && count >= max_keep) break;
+        for (int w = c + 1 + tid; w < W; w += REDUCE_THREADS) {
+            uint64_t acc = removed[w];
+            uint64_t k = kept;
+            while (k) {
+                const int b = __ffsll((long long)k) - 1;
+                k &= k - 1;
+                acc |= segm[(size_t)(c * 64 + b) * words + w];
+            }
+            removed[w] = acc;
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        int count = *s_count;
+        if (max_keep > 0 && count > max_keep) count = max_keep;
+        counters[seg * CNT_STRIDE + CNT_KEEP] = count;
+    }
+}
+
+// Largest candidate count the bitmask path accepts: the mask is cap^2/8 bytes per image.
+constexpr long long NMS_MAX_CAND = 262144;
+
+template <typename T>
+int nms_sorted(fd_ctx* ctx, const T* cand_boxes, int32_t* counters, int cap, int nseg, T thresh, int max_keep,
+               int32_t* keep, hipStream_t stream) {
+    if (cap <= 0 || nseg <= 0) return FD_OK;
+    if (cap > NMS_MAX_CAND) {
+        set_error("nms: %d candidates per image exceed the limit of %lld", cap, NMS_MAX_CAND);
+        return FD_ERR_LIMIT;
+    }
+    const int words = ceil_div(cap, 64);
+    uint64_t* mask = nullptr;
+    FD_TRY(scratch_as(ctx, SLOT_NMS_MASK, (size_t)nseg * cap * words, &mask));
+    dim3 grid(words, words, nseg);
+    hipLaunchKernelGGL(nms_mask_kernel<T>, grid, dim3(64), 0, stream, cand_boxes, counters, cap, words, thresh, mask);
+    FD_LAUNCH_CHECK();
+    const size_t smem = (size_t)words * 8 + 16;
+    hipLaunchKernelGGL(nms_reduce_kernel, dim3(nseg), dim3(REDUCE_THREADS), smem, stream, mask, counters, cap, words,
+                       max_keep, keep);
+    FD_LAUNCH_CHECK();
+    return FD_OK;
+}
+template int nms_sorted<float>(fd_ctx*, const float*, int32_t*, int, int, float, int, int32_t*, hipStream_t);
+template int nms_sorted<double>(fd_ctx*, const double*, int32_t*, int, int, double, int, int32_t*, hipStream_t);
+
+// ---------------------------------------------------------------------------------
+// Candidate gather: boxes / scores of the first n_cand sorted entries.
+// ---------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void gather_candidates_kernel(const uint32_t* __restrict__ sorted_idx,
+                                                               const T* __restrict__ boxes,
+                                                               const float* __restrict__ scores, int n, int cap,
+                                                               int32_t* __restrict__ counters, T* __restrict__ cand_boxes,
+                                                               float* __restrict__ cand_scores,
+                                                               int32_t* __restrict__ cand_index) {
+    const int seg = blockIdx.y;
+    const int n_valid = counters[seg * CNT_STRIDE + CNT_VALID];
+    const int n_cand = min(n_valid, cap);
+    const int r = blockIdx.x * 256 + threadIdx.x;
+    if (r == 0) counters[seg * CNT_STRIDE + CNT_CAND] = n_cand;
+    if (r >= n_cand) return;
+    const uint32_t idx = sorted_idx[(size_t)seg * n + r];
+    const T* b = boxes + ((size_t)seg * n + idx) * 4;
+    T* o = cand_boxes + ((size_t)seg * cap + r) * 4;
+    o[0] = b[0]; o[1] = b[1]; o[2] = b[2]; o[3] = b[3];
+    if (cand_scores) cand_scores[(size_t)seg * cap + r] = scores[(size_t)seg * n + idx];
+    cand_index[(size_t)seg * cap + r] = (int32_t)idx;
+}
+
+// ---------------------------------------------------------------------------------
+// Shared decode arithmetic (processing.py:47-76): float32 deltas, exp() in float32,
+// everything else in T.
+// ---------------------------------------------------------------------------------
+template <typename T>
+__device__ __forceinline__ void decode_box(T bx1, T by1, T bx2, T by2, float dx, float dy, float dw, float dh,
+                                           T& ox1, T& oy1, T& ox2, T& oy2) {
+    const T w = bx2 - bx1 + T(1);
+    const T h = by2 - by1 + T(1);
+    const T cx = bx1 + T(0.5) * (w - T(1));
+    const T cy = by1 + T(0.5) * (h - T(1));
+    const T pcx = T(dx) * w + cx;
+    const T pcy = T(dy) * h + cy;
+    const T pw = T(expf(dw)) * w;
+    const T ph = T(expf(dh)) * h;
+    ox1 = pcx - T(0.5) * (pw - T(1));
+    oy1 = pcy - T(0.5) * (ph - T(1));
+    ox2 = pcx + T(0.5) * (pw - T(1));
+    oy2 = pcy + T(0.5) * (ph - T(1));
+}
+__device__ __forceinline__ float tmax(float a, float b) { return fmaxf(a, b); }
+__device__ __forceinline__ double tmax(double a, double b) { return fmax(a, b); }
+__device__ __forceinline__ float tmin(float a, float b) { return fminf(a, b); }
+__device__ __forceinline__ double tmin(double a, double b) { return fmin(a, b); }
+template <typename T>
+__device__ __forceinline__ T clampT(T v, T hi) { return tmax(tmin(v, hi), T(0)); }
+
+// Anchor table and image info travel as kernel arguments: no host->device copy whose
+// source would have to outlive the call.
+constexpr int MAX_ANCHORS = 32;
+template <typename T>
+struct AnchorTable {
+    T v[MAX_ANCHORS * 4];
+};
+
+// ---------------------------------------------------------------------------------
+// RPN proposal: decode + clip + min-size filter for every anchor (proposal.py:60-103).
+// Entry N-1-idx of the sort input holds anchor idx, so the stable sort breaks score
+// ties towards the higher anchor index.
+// ---------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void proposal_decode_kernel(const float* __restrict__ cls,
+                                                             const float* __restrict__ bbox, RpnLayout lay, int softmax,
+                                                             AnchorTable<T> anchors, int A, int H, int W,
+                                                             int feat_stride, const float* __restrict__ im_info,
+                                                             float info_h, float info_w, float info_s,
+                                                             float min_size, T* __restrict__ boxes,
+                                                             float* __restrict__ scores, uint32_t* __restrict__ keys,
+                                                             uint32_t* __restrict__ vals, int32_t* __restrict__ counters,
+                                                             int32_t* __restrict__ nan_flag) {
+    const int seg = blockIdx.y;
+    const int N = H * W * A;
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    bool valid = false;
+    if (idx < N) {
+        const int a = idx % A;
+        const int w = (idx / A) % W;
+        const int h = idx / (A * W);
+        const long long cbase = seg * lay.cls_batch + a * lay.cls_anchor + h * lay.cls_h + w * lay.cls_w;
+        float score = cls[cbase + lay.cls_fg_off];
+        if (softmax) {
+            const float bg = cls[cbase + lay.cls_bg_off];
+            const float m = fmaxf(bg, score);
+            const float eb = expf(bg - m), ef = expf(score - m);
+            score = ef / (eb + ef);
+        }
+        const long long bbase = seg * lay.box_batch + lay.box_off + h * lay.box_h + w * lay.box_w;
+        const float dx = bbox[bbase + (4 * a + 0) * lay.box_chan];
+        const float dy = bbox[bbase + (4 * a + 1) * lay.box_chan];
+        const float dw = bbox[bbase + (4 * a + 2) * lay.box_chan];
+        const float dh = bbox[bbase + (4 * a + 3) * lay.box_chan];
+        if (nan_flag && (isnan(score) || isnan(dx) || isnan(dy) || isnan(dw) || isnan(dh))) atomicOr(nan_flag, 1);
+        const T sx = T(w * feat_stride), sy = T(h * feat_stride);
+        T x1, y1, x2, y2;
+        decode_box<T>(anchors.v[a * 4 + 0] + sx, anchors.v[a * 4 + 1] + sy, anchors.v[a * 4 + 2] + sx,
+                      anchors.v[a * 4 + 3] + sy, dx, dy, dw, dh, x1, y1, x2, y2);
+        const float im_h = im_info ? im_info[seg * 3 + 0] : info_h;
+        const float im_w = im_info ? im_info[seg * 3 + 1] : info_w;
+        const float im_s = im_info ? im_info[seg * 3 + 2] : info_s;
+        const T wmax = T(im_w - 1.0f), hmax = T(im_h - 1.0f);
+        x1 = clampT(x1, wmax); y1 = clampT(y1, hmax);
+        x2 = clampT(x2, wmax); y2 = clampT(y2, hmax);
+        const T lim = T(min_size * im_s);
+        valid = ((x2 - x1 + T(1)) >= lim) && ((y2 - y1 + T(1)) >= lim);
+        T* ob = boxes + ((size_t)seg * N + idx) * 4;
+        ob[0] = x1; ob[1] = y1; ob[2] = x2; ob[3] = y2;
+        scores[(size_t)seg * N + idx] = score;
+        const size_t p = (size_t)seg * N + (N - 1 - idx);
+        keys[p] = valid ? desc_key(score) : KEY_INVALID32;
+        vals[p] = (uint32_t)idx;
+    }
+    const uint64_t m = __ballot(valid);
+    if ((threadIdx.x & 63) == 0 && m) atomicAdd(&counters[seg * CNT_STRIDE + CNT_VALID], (int)__popcll(m));
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void proposal_output_kernel(const T* __restrict__ cand_boxes,
+                                                             const float* __restrict__ cand_scores,
+                                                             const int32_t* __restrict__ keep,
+                                                             const int32_t* __restrict__ counters, int cap, int post_n,
+                                                             float* __restrict__ rois, float* __restrict__ roi_scores,
+                                                             int32_t* __restrict__ counts_out) {
+    const int seg = blockIdx.y;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int nk = min(counters[seg * CNT_STRIDE + CNT_KEEP], post_n);
+    if (i == 0 && counts_out) {
+        counts_out[seg * 3 + 0] = counters[seg * CNT_STRIDE + CNT_VALID];
+        counts_out[seg * 3 + 1] = counters[seg * CNT_STRIDE + CNT_CAND];
+        counts_out[seg * 3 + 2] = nk;
+    }
+    if (i >= post_n) return;
+    float* o = rois + ((size_t)seg * post_n + i) * 5;
+    float sc = 0.0f;
+    if (nk == 0) {
+        o[0] = (float)seg; o[1] = o[2] = o[3] = o[4] = 0.0f;
+    } else {
+        const int r = keep[(size_t)seg * cap + (i % nk)];   // cyclic padding of a short keep list
+        const T* b = cand_boxes + ((size_t)seg * cap + r) * 4;
+        o[0] = (float)seg;
+        o[1] = (float)b[0]; o[2] = (float)b[1]; o[3] = (float)b[2]; o[4] = (float)b[3];
+        sc = cand_scores[(size_t)seg * cap + r];
+    }
+    if (roi_scores) roi_scores[(size_t)seg * post_n + i] = sc;
+}
+
+template <typename T>
+static int proposal_run_t(fd_ctx* ctx, const fd_proposal_cfg* cfg, const float* cls, const float* bbox,
+                          const RpnLayout& lay, int softmax, const float* im_info_dev, const float* info_uniform,
+                          int batch, int H, int W,
+                          float* rois, float* roi_scores, int32_t* counts, int32_t* nan_flag, hipStream_t stream) {
+    const int A = cfg->num_ratios * cfg->num_scales;
+    const long long N_ll = (long long)H * W * A;
+    if (N_ll > (1ll << 24)) {
+        set_error("proposal: %lld anchors per image exceed the limit of %d", N_ll, 1 << 24);
+        return FD_ERR_LIMIT;
+    }
+    const int N = (int)N_ll;
+    const int cap = (cfg->pre_nms_top_n > 0 && cfg->pre_nms_top_n < N) ? cfg->pre_nms_top_n : N;
+    const int post_n = cfg->post_nms_top_n;
+
+    // anchor table (host, float64, exact) -> device in T
+    double ratios[8], scales[8], anc[64 * 4];
+    for (int i = 0; i < cfg->num_ratios; ++i) ratios[i] = cfg->ratios[i];
+    for (int i = 0; i < cfg->num_scales; ++i) scales[i] = cfg->scales[i];
+    FD_TRY(fd_generate_anchors((double)cfg->feat_stride, ratios, cfg->num_ratios, scales, cfg->num_scales, anc));
+    AnchorTable<T> anchors;
+    memset(&anchors, 0, sizeof(anchors));
+    for (int i = 0; i < A * 4; ++i) anchors.v[i] = (T)anc[i];
+
+    T* boxes = nullptr; float* scores = nullptr;
+    uint32_t *ka = nullptr, *kb = nullptr, *va = nullptr, *vb = nullptr;
+    int32_t* counters = nullptr;
+    T* cand_boxes = nullptr; float* cand_scores = nullptr; int32_t* cand_index = nullptr; int32_t* keep = nullptr;
+    const size_t tot = (size_t)batch * N, ctot = (size_t)batch * cap;
+    FD_TRY(scratch_as(ctx, SLOT_BOXES, tot * 4, &boxes));
+    FD_TRY(scratch_as(ctx, SLOT_SCORES, tot, &scores));
+    FD_TRY(scratch_as(ctx, SLOT_SORT_KEYS_A, tot, &ka));
+    FD_TRY(scratch_as(ctx, SLOT_SORT_KEYS_B, tot, &kb));
+    FD_TRY(scratch_as(ctx, SLOT_SORT_VALS_A, tot, &va));
+    FD_TRY(scratch_as(ctx, SLOT_SORT_VALS_B, tot, &vb));
+    FD_TRY(scratch_as(ctx, SLOT_COUNTERS, (size_t)batch * CNT_STRIDE, &counters));
+    FD_TRY(scratch_as(ctx, SLOT_CAND_BOXES, ctot * 4, &cand_boxes));
+    FD_TRY(scratch_as(ctx, SLOT_CAND_SCORES, ctot, &cand_scores));
+    FD_TRY(scratch_as(ctx, SLOT_CAND_INDEX, ctot, &cand_index));
+    FD_TRY(scratch_as(ctx, SLOT_KEEP, ctot, &keep));
+    FD_HIP(hipMemsetAsync(counters, 0, sizeof(int32_t) * batch * CNT_STRIDE, stream));
+    if (nan_flag) FD_HIP(hipMemsetAsync(nan_flag, 0, sizeof(int32_t), stream));
+
+    hipLaunchKernelGGL(proposal_decode_kernel<T>, dim3(ceil_div(N, 256), batch), dim3(256), 0, stream, cls, bbox, lay,
+                       softmax, anchors, A, H, W, cfg->feat_stride, im_info_dev, info_uniform[0], info_uniform[1],
+                       info_uniform[2], cfg->min_size, boxes, scores, ka, va, counters, nan_flag);
+    FD_LAUNCH_CHECK();
+    FD_TRY(sort_pairs_u32(ctx, ka, va, kb, vb, N, batch, stream));
+    hipLaunchKernelGGL(gather_candidates_kernel<T>, dim3(ceil_div(cap, 256), batch), dim3(256), 0, stream, va, boxes,
+                       scores, N, cap, counters, cand_boxes, cand_scores, cand_index);
+    FD_LAUNCH_CHECK();
+    FD_TRY(nms_sorted<T>(ctx, cand_boxes, counters, cap, batch, (T)cfg->nms_thresh, post_n, keep, stream));
+    hipLaunchKernelGGL(proposal_output_kernel<T>, dim3(ceil_div(post_n, 256), batch), dim3(256), 0, stream, cand_boxes,
+                       cand_scores, keep, counters, cap, post_n, rois, roi_scores, counts);
+    FD_LAUNCH_CHECK();
+    return FD_OK;
+}
+
+int proposal_run(fd_ctx* ctx, const fd_proposal_cfg* cfg, const float* cls, const float* bbox, const RpnLayout& lay,
+                 int softmax, const float* im_info_dev, const float* info_uniform, int batch, int height, int width,
+                 float* rois, float* roi_scores, int32_t* counts, int32_t* nan_flag, hipStream_t stream) {
+    FD_REQUIRE(ctx && cfg && cls && bbox && rois && (im_info_dev || info_uniform), "proposal: NULL argument");
+    static const float zero3[3] = {0.f, 0.f, 0.f};
+    if (!info_uniform) info_uniform = zero3;
+    FD_REQUIRE(batch > 0 && height > 0 && width > 0, "proposal: bad shape %d x %d x %d", batch, height, width);
+    FD_REQUIRE(cfg->num_ratios > 0 && cfg->num_ratios <= 8 && cfg->num_scales > 0 && cfg->num_scales <= 8 &&
+                   cfg->num_ratios * cfg->num_scales <= MAX_ANCHORS,
+               "proposal: 1..8 ratios and scales, at most %d anchors per cell", MAX_ANCHORS);
+    FD_REQUIRE(cfg->post_nms_top_n > 0, "proposal: post_nms_top_n must be > 0");
+    FD_REQUIRE(cfg->feat_stride > 0, "proposal: feat_stride must be > 0");
+    if (cfg->box_f64)
+        return proposal_run_t<double>(ctx, cfg, cls, bbox, lay, softmax, im_info_dev, info_uniform, batch, height,
+                                      width, rois, roi_scores, counts, nan_flag, stream);
+    return proposal_run_t<float>(ctx, cfg, cls, bbox, lay, softmax, im_info_dev, info_uniform, batch, height, width,
+                                 rois, roi_scores, counts, nan_flag, stream);
+}
+
+// ---------------------------------------------------------------------------------
+// Stand-alone nms(dets, thresh).
+// ---------------------------------------------------------------------------------
+template <typename T, typename K>
+__global__ __launch_bounds__(256) void nms_prepare_kernel(const T* __restrict__ dets, int n, T* __restrict__ boxes,
+                                                         K* __restrict__ keys, uint32_t* __restrict__ vals) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const T* d = dets + (size_t)i * 5;
+    boxes[(size_t)i * 4 + 0] = d[0];
+    boxes[(size_t)i * 4 + 1] = d[1];
+    boxes[(size_t)i * 4 + 2] = d[2];
+    boxes[(size_t)i * 4 + 3] = d[3];
+    keys[n - 1 - i] = desc_key(d[4]);
+    vals[n - 1 - i] = (uint32_t)i;
+}
+
+__global__ __launch_bounds__(256) void set_counters_kernel(int32_t* counters, int n_valid) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        counters[CNT_VALID] = n_valid;
+        counters[CNT_CAND] = 0;
+        counters[CNT_KEEP] = 0;
+    }
+}
+
+__global__ __launch_bounds__(256) void nms_finish_kernel(const int32_t* __restrict__ keep_ranks,
+                                                        const int32_t* __restrict__ cand_index,
+                                                        const int32_t* __restrict__ counters, int n,
+                                                        int32_t* __restrict__ keep_out, int32_t* __restrict__ n_keep) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int nk = counters[CNT_KEEP];
+    if (i == 0) *n_keep = nk;
+    if (i < nk) keep_out[i] = cand_index[keep_ranks[i]];
+}
+
+template <typename T, typename K>
+static int nms_standalone(fd_ctx* ctx, const T* dets, int n, T thresh, int32_t* keep_out, int32_t* n_keep,
+                          hipStream_t stream) {
+    FD_REQUIRE(ctx && n_keep && n >= 0, "nms: bad arguments");
+    if (n == 0) {
+        FD_HIP(hipMemsetAsync(n_keep, 0, sizeof(int32_t), stream));
+        return FD_OK;
+    }
+    FD_REQUIRE(dets && keep_out, "nms: NULL dets / keep");
+    if (n > NMS_MAX_CAND) {
+        set_error("nms: %d boxes exceed the limit of %lld", n, NMS_MAX_CAND);
+        return FD_ERR_LIMIT;
+    }
+    T *boxes = nullptr, *cand_boxes = nullptr;
+    K *ka = nullptr, *kb = nullptr;
+    uint32_t *va = nullptr, *vb = nullptr;
+    int32_t *counters = nullptr, *cand_index = nullptr, *keep = nullptr;
+    FD_TRY(scratch_as(ctx, SLOT_BOXES, (size_t)n * 4, &boxes));
+    FD_TRY(scratch_as(ctx, SLOT_SORT_KEYS_A, (size_t)n, &ka));
+    FD_TRY(scratch_as(ctx, SLOT_SORT_KEYS_B, (size_t)n, &kb));
+    FD_TRY(scratch_as(ctx, SLOT_SORT_VALS_A, (size_t)n, &va));
+    FD_TRY(scratch_as(ctx, SLOT_SORT_VALS_B, (size_t)n, &vb));
+    FD_TRY(scratch_as(ctx, SLOT_COUNTERS, (size_t)CNT_STRIDE, &counters));
+    FD_TRY(scratch_as(ctx, SLOT_CAND_BOXES, (size_t)n * 4, &cand_boxes));
+    FD_TRY(scratch_as(ctx, SLOT_CAND_INDEX, (size_t)n, &cand_index));
+    FD_TRY(scratch_as(ctx, SLOT_KEEP, (size_t)n, &keep));
+    const int nb = ceil_div(n, 256);
+    hipLaunchKernelGGL((nms_prepare_kernel<T, K>), dim3(nb), dim3(256), 0, stream, dets, n, boxes, ka, va);
+    FD_LAUNCH_CHECK();
+    hipLaunchKernelGGL(set_counters_kernel, dim3(1), dim3(256), 0, stream, counters, n);
+    FD_LAUNCH_CHECK();
+    FD_TRY((sort_pairs<K>(ctx, ka, va, kb, vb, n, 1, stream)));
+    hipLaunchKernelGGL(gather_candidates_kernel<T>, dim3(nb, 1), dim3(256), 0, stream, va, boxes,
+                       (const float*)nullptr, n, n, counters, cand_boxes, (float*)nullptr, cand_index);
+    FD_LAUNCH_CHECK();
+    FD_TRY(nms_sorted<T>(ctx, cand_boxes, counters, n, 1, thresh, 0, keep, stream));
+    hipLaunchKernelGGL(nms_finish_kernel, dim3(nb), dim3(256), 0, stream, keep, cand_index, counters, n, keep_out,
+                       n_keep);
+    FD_LAUNCH_CHECK();
+    return FD_OK;
+}
+
+// ---------------------------------------------------------------------------------
+// bbox_pred (+ clip_boxes) as a stand-alone stage.
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void bbox_pred_kernel(const float* __restrict__ boxes, const float* __restrict__ deltas,
+                                                       int n, int C, int clip, double hmax, double wmax,
+                                                       double* __restrict__ out) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= n * C) return;
+    const int i = t / C, c = t % C;
+    const float* b = boxes + (size_t)i * 4;
+    const float* d = deltas + (size_t)i * 4 * C + 4 * c;
+    double x1, y1, x2, y2;
+    decode_box<double>((double)b[0], (double)b[1], (double)b[2], (double)b[3], d[0], d[1], d[2], d[3], x1, y1, x2, y2);
+    if (clip) {
+        x1 = clampT(x1, wmax); y1 = clampT(y1, hmax);
+        x2 = clampT(x2, wmax); y2 = clampT(y2, hmax);
+    }
+    double* o = out + (size_t)i * 4 * C + 4 * c;
+    o[0] = x1; o[1] = y1; o[2] = x2; o[3] = y2;
+}
+
+__global__ __launch_bounds__(256) void clip_boxes_kernel(double* __restrict__ boxes, int total, double hmax,
+                                                        double wmax) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= total) return;
+    boxes[t] = clampT(boxes[t], (t & 1) ? hmax : wmax);   // columns x1,y1,x2,y2 repeat with period 4
+}
+
+// ---------------------------------------------------------------------------------
+// Detector tail (detection.py:47-58).
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void head_decode_kernel(const float* __restrict__ rois, int roi_stride,
+                                                         const float* __restrict__ scores,
+                                                         const float* __restrict__ deltas, int R, double hmax,
+                                                         double wmax, float thresh, float* __restrict__ boxes,
+                                                         float* __restrict__ out_scores, uint32_t* __restrict__ keys,
+                                                         uint32_t* __restrict__ vals, int32_t* __restrict__ counters) {
+    const int seg = blockIdx.y;
+    const int r = blockIdx.x * 256 + threadIdx.x;
+    bool valid = false;
+    if (r < R) {
+        const size_t g = (size_t)seg * R + r;
+        const float* b = rois + g * roi_stride + (roi_stride - 4);
+        const float* d = deltas + g * 8 + 4;   // class 1
+        double x1, y1, x2, y2;
+        decode_box<double>((double)b[0], (double)b[1], (double)b[2], (double)b[3], d[0], d[1], d[2], d[3], x1, y1, x2,
+                           y2);
+        x1 = clampT(x1, wmax); y1 = clampT(y1, hmax);
+        x2 = clampT(x2, wmax); y2 = clampT(y2, hmax);
+        const float s = scores[g * 2 + 1];
+        valid = s >= thresh;
+        boxes[g * 4 + 0] = (float)x1; boxes[g * 4 + 1] = (float)y1;
+        boxes[g * 4 + 2] = (float)x2; boxes[g * 4 + 3] = (float)y2;
+        out_scores[g] = s;
+        const size_t p = (size_t)seg * R + (R - 1 - r);
+        keys[p] = valid ? desc_key(s) : KEY_INVALID32;
+        vals[p] = (uint32_t)r;
+    }
+    const uint64_t m = __ballot(valid);
+    if ((threadIdx.x & 63) == 0 && m) atomicAdd(&counters[seg * CNT_STRIDE + CNT_VALID], (int)__popcll(m));
+}
+
+__global__ __launch_bounds__(256) void dets_output_kernel(const float* __restrict__ cand_boxes,
+                                                         const float* __restrict__ cand_scores,
+                                                         const int32_t* __restrict__ keep,
+                                                         const int32_t* __restrict__ counters, int R, int do_round,
+                                                         float* __restrict__ dets, int32_t* __restrict__ n_dets) {
+    const int seg = blockIdx.y;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int nk = counters[seg * CNT_STRIDE + CNT_KEEP];
+    if (i == 0) n_dets[seg] = nk;
+    if (i >= R) return;
+    float* o = dets + ((size_t)seg * R + i) * 5;
+    if (i >= nk) {
+        o[0] = o[1] = o[2] = o[3] = o[4] = 0.0f;
+        return;
+    }
+    const int r = keep[(size_t)seg * R + i];
+    const float* b = cand_boxes + ((size_t)seg * R + r) * 4;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        float v = b[k];
+        if (do_round) v = (float)(int)rintf(v);   // round half to even, through int32 as the reference does
+        o[k] = v;
+    }
+    o[4] = cand_scores[(size_t)seg * R + r];
+}
+
+int postprocess_run(fd_ctx* ctx, const float* rois, int roi_stride, const float* scores, const float* deltas,
+                    int batch, int R, int im_h, int im_w, float thresh, float nms_thresh, int do_round, float* dets,
+                    int32_t* n_dets, hipStream_t stream) {
+    FD_REQUIRE(ctx && n_dets && batch > 0 && R >= 0, "postprocess: bad arguments");
+    FD_REQUIRE(roi_stride == 4 || roi_stride == 5, "postprocess: roi rows must have 4 or 5 columns");
+    if (R == 0) {
+        FD_HIP(hipMemsetAsync(n_dets, 0, sizeof(int32_t) * batch, stream));
+        return FD_OK;
+    }
+    FD_REQUIRE(rois && scores && deltas && dets, "postprocess: NULL argument");
+    float *boxes = nullptr, *sc = nullptr, *cand_boxes = nullptr, *cand_scores = nullptr;
+    uint32_t *ka = nullptr, *kb = nullptr, *va = nullptr, *vb = nullptr;
+    int32_t *counters = nullptr, *cand_index = nullptr, *keep = nullptr;
+    const size_t tot = (size_t)batch * R;
+    FD_TRY(scratch_as(ctx, SLOT_BOXES, tot * 4, &boxes));
+    FD_TRY(scratch_as(ctx, SLOT_SCORES, tot, &sc));
+    FD_TRY(scratch_as(ctx, SLOT_SORT_KEYS_A, tot, &ka));
+    FD_TRY(scratch_as(ctx, SLOT_SORT_KEYS_B, tot, &kb));
+    FD_TRY(scratch_as(ctx, SLOT_SORT_VALS_A, tot, &va));
+    FD_TRY(scratch_as(ctx, SLOT_SORT_VALS_B, tot, &vb));
+    FD_TRY(scratch_as(ctx, SLOT_COUNTERS, (size_t)batch * CNT_STRIDE, &counters));
+    FD_TRY(scratch_as(ctx, SLOT_CAND_BOXES, tot * 4, &cand_boxes));
+    FD_TRY(scratch_as(ctx, SLOT_CAND_SCORES, tot, &cand_scores));
+    FD_TRY(scratch_as(ctx, SLOT_CAND_INDEX, tot, &cand_index));
+    FD_TRY(scratch_as(ctx, SLOT_KEEP, tot, &keep));
+    FD_HIP(hipMemsetAsync(counters, 0, sizeof(int32_t) * batch * CNT_STRIDE, stream));
+    dim3 grid(ceil_div(R, 256), batch);
+    hipLaunchKernelGGL(head_decode_kernel, grid, dim3(256), 0, stream, rois, roi_stride, scores, deltas, R,
+                       (double)(im_h - 1), (double)(im_w - 1), thresh, boxes, sc, ka, va, counters);
+    FD_LAUNCH_CHECK();
+    FD_TRY(sort_pairs_u32(ctx, ka, va, kb, vb, R, batch, stream));
+    hipLaunchKernelGGL(gather_candidates_kernel<float>, grid, dim3(256), 0, stream, va, boxes, sc, R, R, counters,
+                       cand_boxes, cand_scores, cand_index);
+    FD_LAUNCH_CHECK();
+    FD_TRY(nms_sorted<float>(ctx, cand_boxes, counters, R, batch, nms_thresh, 0, keep, stream));
+    hipLaunchKernelGGL(dets_output_kernel, grid, dim3(256), 0, stream, cand_boxes, cand_scores, keep, counters, R,
+                       do_round, dets, n_dets);
+    FD_LAUNCH_CHECK();
+    return FD_OK;
+}
+
+// ---------------------------------------------------------------------------------
+// ROI max pooling (MXNet ROIPooling semantics: box corners scaled and rounded half away
+// from zero, bins split with floor/ceil edges, empty bin -> 0).
+// ---------------------------------------------------------------------------------
+struct RoiBin {
+    int b, hstart, hend, wstart, wend;
+    bool empty;
+};
+__device__ __forceinline__ RoiBin roi_bin(const float* roi, float scale, int ph, int pw, int PH, int PW, int H, int W,
+                                          int batch) {
+    RoiBin r;
+    r.b = (int)roi[0];
+    const int sw = (int)roundf(roi[1] * scale), sh = (int)roundf(roi[2] * scale);
+    const int ew = (int)roundf(roi[3] * scale), eh = (int)roundf(roi[4] * scale);
+    const int rh = max(eh - sh + 1, 1), rw = max(ew - sw + 1, 1);
+    const float bh = (float)rh / (float)PH, bw = (float)rw / (float)PW;
+    int hs = (int)floorf((float)ph * bh), ws = (int)floorf((float)pw * bw);
+    int he = (int)ceilf((float)(ph + 1) * bh), we = (int)ceilf((float)(pw + 1) * bw);
+    r.hstart = min(max(hs + sh, 0), H);
+    r.hend = min(max(he + sh, 0), H);
+    r.wstart = min(max(ws + sw, 0), W);
+    r.wend = min(max(we + sw, 0), W);
+    r.empty = (r.hend <= r.hstart) || (r.wend <= r.wstart) || r.b < 0 || r.b >= batch;
+    return r;
+}
+
+__global__ __launch_bounds__(256) void roipool_nchw_kernel(const float* __restrict__ data, int batch, int C, int H, int W,
+                                                          const float* __restrict__ rois, int num_rois, int PH, int PW,
+                                                          float scale, float* __restrict__ out) {
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long total = (long long)num_rois * C * PH * PW;
+    if (t >= total) return;
+    const int pw = (int)(t % PW);
+    const int ph = (int)((t / PW) % PH);
+    const int c = (int)((t / ((long long)PW * PH)) % C);
+    const int n = (int)(t / ((long long)PW * PH * C));
+    const RoiBin r = roi_bin(rois + (size_t)n * 5, scale, ph, pw, PH, PW, H, W, batch);
+    float m = 0.0f;
+    if (!r.empty) {
+        m = -FLT_MAX;
+        const float* p = data + ((size_t)r.b * C + c) * H * W;
+        for (int h = r.hstart; h < r.hend; ++h)
+            for (int w = r.wstart; w < r.wend; ++w) m = fmaxf(m, p[h * W + w]);
+    }
+    out[t] = m;
+}
+
+// channels-last: one block per (roi, bin); threads sweep the channels 4 at a time
+__global__ __launch_bounds__(256) void roipool_nhwc_kernel(const float* __restrict__ data, int batch, int C, int H, int W,
+                                                          const float* __restrict__ rois, int num_rois, int PH, int PW,
+                                                          float scale, float* __restrict__ out) {
+    const int bin = blockIdx.x, n = blockIdx.y;
+    const int ph = bin / PW, pw = bin % PW;
+    const RoiBin r = roi_bin(rois + (size_t)n * 5, scale, ph, pw, PH, PW, H, W, batch);
+    float4* o = reinterpret_cast<float4*>(out + ((size_t)n * PH * PW + bin) * C);
+    for (int c4 = threadIdx.x; c4 < C / 4; c4 += 256) {
+        float4 m = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (!r.empty) {
+            m = make_float4(-FLT_MAX, -FLT_MAX, -FLT_MAX, -FLT_MAX);
+            for (int h = r.hstart; h < r.hend; ++h)
+                for (int w = r.wstart; w < r.wend; ++w) {
+                    const float4 v =
+                        reinterpret_cast<const float4*>(data + (((size_t)r.b * H + h) * W + w) * C)[c4];
+                    m.x = fmaxf(m.x, v.x); m.y = fmaxf(m.y, v.y); m.z = fmaxf(m.z, v.z); m.w = fmaxf(m.w, v.w);
+                }
+        }
+        o[c4] = m;
+    }
+}
+
+int roipool_nhwc(const float* data, int batch, int C, int H, int W, const float* rois, int num_rois, int PH, int PW,
+                 float scale, float* out, hipStream_t stream) {
+    FD_REQUIRE(data && rois && out, "roipool: NULL argument");
+    FD_REQUIRE(C % 4 == 0 && C > 0, "roipool (channels-last): channel count %d must be a multiple of 4", C);
+    if (num_rois <= 0) return FD_OK;
+    hipLaunchKernelGGL(roipool_nhwc_kernel, dim3(PH * PW, num_rois), dim3(256), 0, stream, data, batch, C, H, W, rois,
+                       num_rois, PH, PW, scale, out);
+    FD_LAUNCH_CHECK();
+    return FD_OK;
+}
+
+}  // namespace fd
+
+// =================================================================================
+// C ABI
+// =================================================================================
+extern "C" {
+
+int fd_bbox_pred_f64(fd_ctx* ctx, const float* boxes, const float* deltas, int n, int num_classes, int clip,
+                     double im_h, double im_w, double* out, void* stream) {
+    (void)ctx;
+    FD_REQUIRE(n >= 0 && num_classes > 0, "fd_bbox_pred_f64: bad shape");
+    if (n == 0) return FD_OK;
+    FD_REQUIRE(boxes && deltas && out, "fd_bbox_pred_f64: NULL argument");
+    hipLaunchKernelGGL(fd::bbox_pred_kernel, dim3(fd::ceil_div((long long)n * num_classes, 256)), dim3(256), 0,
+                       fd::as_stream(stream), boxes, deltas, n, num_classes, clip, im_h - 1.0, im_w - 1.0, out);
+    FD_LAUNCH_CHECK();
+    return FD_OK;
+}
+
+int fd_clip_boxes_f64(fd_ctx* ctx, double* boxes, int n, int num_classes, double im_h, double im_w, void* stream) {
+    (void)ctx;
+    FD_REQUIRE(n >= 0 && num_classes > 0, "fd_clip_boxes_f64: bad shape");
+    if (n == 0) return FD_OK;
+    FD_REQUIRE(boxes, "fd_clip_boxes_f64: NULL argument");
+    const int total = n * num_classes * 4;
+    hipLaunchKernelGGL(fd::clip_boxes_kernel, dim3(fd::ceil_div(total, 256)), dim3(256), 0, fd::as_stream(stream),
+                       boxes, total, im_h - 1.0, im_w - 1.0);
+    FD_LAUNCH_CHECK();
+    return FD_OK;
+}
+
+int fd_nms_f32(fd_ctx* ctx, const float* dets, int n, float thresh, int32_t* keep, int32_t* n_keep, void* stream) {
+    return fd::nms_standalone<float, uint32_t>(ctx, dets, n, thresh, keep, n_keep, fd::as_stream(stream));
+}
+
+int fd_nms_f64(fd_ctx* ctx, const double* dets, int n, double thresh, int32_t* keep, int32_t* n_keep, void* stream) {
+    return fd::nms_standalone<double, uint64_t>(ctx, dets, n, thresh, keep, n_keep, fd::as_stream(stream));
+}
+
+int fd_proposal(fd_ctx* ctx, const fd_proposal_cfg* cfg, const float* cls_prob, const float* bbox_pred,
+                const float* im_info_host, int batch, int height, int width, float* rois, float* roi_scores,
+                int32_t* counts, int32_t* nan_flag, void* stream) {
+    FD_REQUIRE(ctx && cfg && im_info_host && batch > 0, "fd_proposal: bad arguments");
+    const int A = cfg->num_ratios * cfg->num_scales;
+    const long long HW = (long long)height * width;
+    fd::RpnLayout lay;
+    lay.cls_batch = 2ll * A * HW; lay.cls_anchor = HW; lay.cls_h = width; lay.cls_w = 1;
+    lay.cls_bg_off = 0; lay.cls_fg_off = (long long)A * HW;
+    lay.box_batch = 4ll * A * HW; lay.box_chan = HW; lay.box_h = width; lay.box_w = 1; lay.box_off = 0;
+    bool uniform = true;
+    for (int b = 1; b < batch && uniform; ++b)
+        for (int k = 0; k < 3; ++k) uniform = uniform && (im_info_host[b * 3 + k] == im_info_host[k]);
+    float* d_info = nullptr;
+    if (!uniform) {
+        // per-image sizes: a blocking copy, so the caller's array need not outlive the call
+        FD_TRY(fd::scratch_as(ctx, fd::SLOT_IMINFO, (size_t)batch * 3, &d_info));
+        FD_HIP(hipStreamSynchronize(fd::as_stream(stream)));
+        FD_HIP(hipMemcpy(d_info, im_info_host, sizeof(float) * 3 * batch, hipMemcpyHostToDevice));
+    }
+    return fd::proposal_run(ctx, cfg, cls_prob, bbox_pred, lay, 0, d_info, im_info_host, batch, height, width, rois,
+                            roi_scores, counts, nan_flag, fd::as_stream(stream));
+}
+
+int fd_roipool(fd_ctx* ctx, const float* data, int batch, int channels, int height, int width, const float* rois,
+               int num_rois, int pooled_h, int pooled_w, float spatial_scale, float* out, void* stream) {
+    (void)ctx;
+    FD_REQUIRE(batch > 0 && channels > 0 && height > 0 && width > 0 && pooled_h > 0 && pooled_w > 0 && num_rois >= 0,
+               "fd_roipool: bad shape");
+    if (num_rois == 0) return FD_OK;
+    FD_REQUIRE(data && rois && out, "fd_roipool: NULL argument");
+    const long long total = (long long)num_rois * channels * pooled_h * pooled_w;
+    hipLaunchKernelGGL(fd::roipool_nchw_kernel, dim3(fd::ceil_div(total, 256)), dim3(256), 0, fd::as_stream(stream),
+                       data, batch, channels, height, width, rois, num_rois, pooled_h, pooled_w, spatial_scale, out);
+    FD_LAUNCH_CHECK();
+    return FD_OK;
+}
+
+int fd_postprocess(fd_ctx* ctx, const float* rois, const float* scores, const float* deltas, int num_rois, int im_h,
+                   int im_w, float thresh, float nms_thresh, int do_round, float* dets, int32_t* n_dets,
+                   void* stream) {
+    return fd::postprocess_run(ctx, rois, 4, scores, deltas, 1, num_rois, im_h, im_w, thresh, nms_thresh, do_round,
+                               dets, n_dets, fd::as_stream(stream));
+}
+
+}  // extern "C"

@@ -1,0 +1,105 @@
+// Shared host-side plumbing of the detection library: error reporting, the
+// per-GPU context and its grow-only scratch slots.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+#include <vector>
+
+#include "../../include/facedet.h"
+
+namespace fd {
+
+void set_error(const char* fmt, ...) __attribute__((format(printf, 1, 2)));
+
+#define FD_HIP(call)                                                                              \
+    do {                                                                                          \
+        hipError_t fd_e_ = (call);                                                                \
+        if (fd_e_ != hipSuccess) {                                                                \
+            ::fd::set_error("%s:%d: %s failed: %s", __FILE__, __LINE__, #call, hipGetErrorString(fd_e_)); \
+            return FD_ERR_HIP;                                                                    \
+        }                                                                                         \
+    } while (0)
+
+#define FD_TRY(expr)                  \
+    do {                              \
+        int fd_rc_ = (expr);          \
+        if (fd_rc_ != FD_OK) return fd_rc_; \
+    } while (0)
+
+#define FD_REQUIRE(cond, ...)              \
+    do {                                   \
+        if (!(cond)) {                     \
+            ::fd::set_error(__VA_ARGS__);  \
+            return FD_ERR_ARG;             \
+        }                                  \
+    } while (0)
+
+// Launch check: catches bad launch configurations at the call site.
+#define FD_LAUNCH_CHECK() FD_HIP(hipGetLastError())
+
+// Scratch slots.  Each slot is one device allocation that only ever grows; a
+// replaced allocation is parked until the context is destroyed because kernels
+// already queued on the stream may still be using it.
+enum Slot {
+    SLOT_SORT_KEYS_A = 0,
+    SLOT_SORT_KEYS_B,
+    SLOT_SORT_VALS_A,
+    SLOT_SORT_VALS_B,
+    SLOT_SORT_HIST,
+    SLOT_BOXES,        // decoded boxes of every anchor / roi
+    SLOT_SCORES,       // score of every anchor / roi
+    SLOT_CAND_BOXES,   // boxes of the sorted candidates
+    SLOT_CAND_SCORES,
+    SLOT_CAND_INDEX,
+    SLOT_COUNTERS,     // small int32 block: n_valid / n_cand / n_keep per image
+    SLOT_NMS_MASK,
+    SLOT_KEEP,
+    SLOT_ANCHORS,
+    SLOT_IMINFO,
+    SLOT_MISC0,
+    SLOT_MISC1,
+    SLOT_MISC2,
+    SLOT_NET0,         // network activations (ping-pong + side buffers)
+    SLOT_NET1,
+    SLOT_NET2,
+    SLOT_NET3,
+    SLOT_NET4,
+    SLOT_NET5,
+    SLOT_NET6,
+    SLOT_NET7,
+    SLOT_COUNT
+};
+
+struct Buf {
+    void* ptr = nullptr;
+    size_t cap = 0;
+};
+
+}  // namespace fd
+
+struct fd_ctx {
+    int device = 0;
+    fd::Buf slots[fd::SLOT_COUNT];
+    std::vector<void*> parked;
+    int64_t bytes = 0;
+};
+
+namespace fd {
+
+// Returns a device buffer of at least `bytes` for `slot` (contents undefined).
+int scratch(fd_ctx* ctx, Slot slot, size_t bytes, void** out);
+
+template <typename T>
+inline int scratch_as(fd_ctx* ctx, Slot slot, size_t count, T** out) {
+    void* p = nullptr;
+    int rc = scratch(ctx, slot, count * sizeof(T), &p);
+    *out = static_cast<T*>(p);
+    return rc;
+}
+
+inline hipStream_t as_stream(void* s) { return static_cast<hipStream_t>(s); }
+
+inline int ceil_div(long long a, long long b) { return (int)((a + b - 1) / b); }
+
+}  // namespace fd

@@ -1,0 +1,107 @@
+"""Operator-level entry points of the detection graph, one per native operator the
+reference graph calls (symbol/faster_rcnn.py:98-103) plus the detector tail
+(detection.py:47-58).  NumPy in -> NumPy out, torch in -> torch (device) out."""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib, runtime
+from .symbol.config import config as _global_config
+
+
+def make_proposal_cfg(feature_stride=16, scales=(4, 8, 16, 32), ratios=(0.5, 1, 2), rpn_pre_nms_top_n=None,
+                      rpn_post_nms_top_n=None, threshold=None, rpn_min_size=None, box_f64=True):
+    """fd_proposal_cfg from the keyword names of ``mx.symbol.contrib.Proposal``; values left
+    at None are read from the global config, as symbol/faster_rcnn.py:100-102 does."""
+    T = _global_config.TEST
+    cfg = _lib.ProposalCfg()
+    cfg.feat_stride = int(feature_stride)
+    scales, ratios = list(scales), list(ratios)
+    if not (0 < len(scales) <= 8 and 0 < len(ratios) <= 8):
+        raise ValueError("between 1 and 8 scales and ratios are supported")
+    cfg.num_scales, cfg.num_ratios = len(scales), len(ratios)
+    for i, s in enumerate(scales):
+        cfg.scales[i] = float(s)
+    for i, r in enumerate(ratios):
+        cfg.ratios[i] = float(r)
+    cfg.pre_nms_top_n = int(T.RPN_PRE_NMS_TOP_N if rpn_pre_nms_top_n is None else rpn_pre_nms_top_n)
+    cfg.post_nms_top_n = int(T.RPN_POST_NMS_TOP_N if rpn_post_nms_top_n is None else rpn_post_nms_top_n)
+    cfg.nms_thresh = float(T.RPN_NMS_THRESH if threshold is None else threshold)
+    cfg.min_size = float(T.RPN_MIN_SIZE if rpn_min_size is None else rpn_min_size)
+    cfg.box_f64 = 1 if box_f64 else 0
+    return cfg
+
+
+def proposal(cls_prob, bbox_pred, im_info, output_score=False, return_counts=False, **kwargs):
+    """``contrib.Proposal``: cls_prob [B,2A,H,W], bbox_pred [B,4A,H,W], im_info [B,3] ->
+    rois [B*post_n, 5].  Raises ValueError on NaN input like the reference operator
+    (proposal.py:47-51).  ``kwargs`` are those of :func:`make_proposal_cfg`."""
+    as_np = not isinstance(cls_prob, torch.Tensor)
+    cfg = make_proposal_cfg(**kwargs)
+    if cfg.post_nms_top_n <= 0:
+        raise ValueError("rpn_post_nms_top_n must be positive (the output has a fixed number of rows)")
+    B, C2, H, W = (int(v) for v in cls_prob.shape)
+    A = cfg.num_scales * cfg.num_ratios
+    if C2 != 2 * A or tuple(int(v) for v in bbox_pred.shape[:2]) != (B, 4 * A):
+        raise ValueError("proposal: cls_prob [B,%d,H,W] and bbox_pred [B,%d,H,W] expected" % (2 * A, 4 * A))
+    ctx = runtime.context()
+    cls_d = runtime.to_device(cls_prob, torch.float32)
+    box_d = runtime.to_device(bbox_pred, torch.float32)
+    if tuple(box_d.shape[2:]) != (H, W):          # clip_pad (processing.py:99-112)
+        box_d = box_d[:, :, :H, :W].contiguous()
+    info = np.ascontiguousarray(np.asarray(im_info.cpu() if isinstance(im_info, torch.Tensor) else im_info,
+                                           dtype=np.float32).reshape(B, 3))
+    rois = runtime.empty((B * cfg.post_nms_top_n, 5), torch.float32)
+    scores = runtime.empty((B * cfg.post_nms_top_n,), torch.float32)
+    counts = runtime.empty((B, 3), torch.int32)
+    nan_flag = runtime.empty((1,), torch.int32)
+    _lib.check(_lib.lib().fd_proposal(ctx.handle, C.byref(cfg), runtime.ptr(cls_d), runtime.ptr(box_d),
+                                      info.ctypes.data_as(_lib.c_f32p), B, H, W, runtime.ptr(rois),
+                                      runtime.ptr(scores), runtime.ptr(counts), runtime.ptr(nan_flag),
+                                      runtime.stream_ptr()))
+    if int(nan_flag.item()) != 0:
+        raise ValueError("there is nan in input scores or bbox_deltas")
+    out = [rois.cpu().numpy() if as_np else rois]
+    if output_score:
+        s = scores.reshape(-1, 1)
+        out.append(s.cpu().numpy() if as_np else s)
+    if return_counts:
+        out.append(counts.cpu().numpy())
+    return out[0] if len(out) == 1 else tuple(out)
+
+
+def roi_pooling(data, rois, pooled_size=(7, 7), spatial_scale=0.0625):
+    """``mx.symbol.ROIPooling``: data [B,C,H,W], rois [R,5] -> [R,C,ph,pw]."""
+    as_np = not isinstance(data, torch.Tensor)
+    B, Cc, H, W = (int(v) for v in data.shape)
+    R = int(rois.shape[0])
+    ph, pw = int(pooled_size[0]), int(pooled_size[1])
+    ctx = runtime.context()
+    d = runtime.to_device(data, torch.float32)
+    r = runtime.to_device(rois, torch.float32)
+    out = runtime.empty((R, Cc, ph, pw), torch.float32)
+    _lib.check(_lib.lib().fd_roipool(ctx.handle, runtime.ptr(d), B, Cc, H, W, runtime.ptr(r), R, ph, pw,
+                                     float(spatial_scale), runtime.ptr(out), runtime.stream_ptr()))
+    return out.cpu().numpy() if as_np else out
+
+
+def postprocess(rois, scores, bbox_deltas, im_shape, thresh=0.8, nms_thresh=0.3, do_round=True):
+    """Detector tail (detection.py:47-58): rois [R,4], scores [R,2], bbox_deltas [R,8] -> dets [n,5] float32."""
+    as_np = not isinstance(rois, torch.Tensor)
+    R = int(rois.shape[0])
+    if R == 0:
+        return np.zeros((0, 5), np.float32) if as_np else torch.zeros((0, 5))
+    ctx = runtime.context()
+    r = runtime.to_device(rois, torch.float32)
+    s = runtime.to_device(scores, torch.float32)
+    d = runtime.to_device(bbox_deltas, torch.float32)
+    dets = runtime.empty((R, 5), torch.float32)
+    n = runtime.empty((1,), torch.int32)
+    _lib.check(_lib.lib().fd_postprocess(ctx.handle, runtime.ptr(r), runtime.ptr(s), runtime.ptr(d), R,
+                                         int(im_shape[0]), int(im_shape[1]), float(thresh), float(nms_thresh),
+                                         1 if do_round else 0, runtime.ptr(dets), runtime.ptr(n),
+                                         runtime.stream_ptr()))
+    k = int(n.item())
+    out = dets[:k]
+    return out.cpu().numpy() if as_np else out
