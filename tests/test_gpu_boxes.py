@@ -39,9 +39,13 @@ def test_bbox_pred_and_clip_vs_reference_vectors(P, golden, tag):
     pred = P.bbox_pred(g["decode_%s_boxes" % tag], g["decode_%s_deltas" % tag])
     assert pred.dtype == np.float64
     ref = g["decode_%s_pred" % tag]
-    # exp() is float32 on both sides but from different libraries (<= 2 ulp apart):
-    # tolerance 4 float32 ulps of the box size, far inside the 0.5 px bar
-    np.testing.assert_allclose(pred, ref, rtol=5e-7, atol=1e-6)
+    # exp() is float32 on both sides but from different libraries (1-2 ulp apart) and that
+    # relative error is multiplied by the predicted box size: allow 3 float32 ulps of it
+    size = np.maximum(ref[:, 2::4] - ref[:, 0::4], ref[:, 3::4] - ref[:, 1::4]) + 1.0
+    tol = np.repeat(3 * 2.0 ** -23 * size, 4, axis=1) + 1e-9
+    assert (np.abs(pred - ref) <= tol).all()
+    small = size < 2000.0                       # for ordinary boxes that is below 1e-3 px
+    assert np.abs(pred - ref)[np.repeat(small, 4, axis=1)].max() < 1e-3
     # the clamp itself is exact: clip the reference's decoded boxes on the GPU
     clipped = P.clip_boxes(ref.copy(), (480, 640))
     np.testing.assert_array_equal(clipped, g["decode_%s_clipped" % tag])
@@ -145,7 +149,7 @@ def test_proposal_vs_reference_vectors(ops, golden, grid, min_size, pre_post):
     assert rois.shape == (post_n, 5) and (rois[:, 0] == 0).all()
     # same boxes in the same order: scores identify them exactly, coordinates agree to float32 exp() rounding
     np.testing.assert_array_equal(scores[:m, 0], g[tag + "_scores"][:m])
-    np.testing.assert_allclose(rois[:m, 1:], g[tag + "_rois"][:m], rtol=1e-6, atol=1e-4)
+    np.testing.assert_allclose(rois[:m, 1:], g[tag + "_rois"][:m], rtol=1e-6, atol=1e-3)
     if 0 < m < post_n:
         np.testing.assert_array_equal(rois[m:], rois[np.arange(m, post_n) % m])
 
@@ -172,7 +176,7 @@ def test_proposal_vs_oracle_batch_and_ties(ops, f64):
         blk = slice(b * 100, (b + 1) * 100)
         assert (rois[blk, 0] == b).all()
         np.testing.assert_array_equal(scores[blk, 0], s)
-        np.testing.assert_allclose(rois[blk, 1:], r[:, 1:], rtol=1e-6, atol=1e-4)
+        np.testing.assert_allclose(rois[blk, 1:], r[:, 1:], rtol=1e-6, atol=1e-3)
 
 
 def test_proposal_no_valid_box_gives_zero_rois(ops):
@@ -207,7 +211,7 @@ def test_proposal_operator_protocol(golden):
         config.TEST.RPN_MIN_SIZE = old
     tag = "prop_g38x50_m24_p1000_q10"
     np.testing.assert_array_equal(out[1][:, 0], g[tag + "_scores"])
-    np.testing.assert_allclose(out[0][:, 1:], g[tag + "_rois"], rtol=1e-6, atol=1e-4)
+    np.testing.assert_allclose(out[0][:, 1:], g[tag + "_rois"], rtol=1e-6, atol=1e-3)
 
 
 # ---------------------------------------------------------------- roi pooling
@@ -239,7 +243,7 @@ def test_postprocess_vs_reference_vectors(ops, golden, R):
     assert np.abs(dets[:, :4] - ref[:, :4]).max() <= 1.0          # rounding of a coordinate 1 ulp apart
     assert (dets[:, :4] == ref[:, :4]).mean() > 0.99
     raw = ops.postprocess(*args, do_round=False)
-    np.testing.assert_allclose(raw, g[tag + "_dets_unrounded"], rtol=1e-6, atol=1e-4)
+    np.testing.assert_allclose(raw, g[tag + "_dets_unrounded"], rtol=1e-6, atol=1e-3)
 
 
 def test_postprocess_nothing_above_threshold(ops):
