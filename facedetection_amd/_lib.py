@@ -32,18 +32,10 @@ class ProposalCfg(C.Structure):
     ]
 
 
-class DetectorCfg(C.Structure):
-    _fields_ = [
-        ("proposal", ProposalCfg),
-        ("max_batch", C.c_int),
-        ("reserved", C.c_int * 7),
-    ]
-
-
 class Param(C.Structure):
     _fields_ = [
         ("name", C.c_char_p),
-        ("data_host", c_f32p),
+        ("data_host", C.c_void_p),
         ("numel", C.c_int64),
     ]
 
@@ -63,6 +55,15 @@ SIGNATURES = {
     "fd_proposal": (C.c_int, [vp, C.POINTER(ProposalCfg), vp, vp, c_f32p, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp]),
     "fd_roipool": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_float, vp, vp]),
     "fd_postprocess": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_int, vp, vp, vp]),
+    "fd_conv2d": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                            vp, vp, vp, C.c_int, vp, vp, vp]),
+    "fd_detector_create": (C.c_int, [vp, C.POINTER(Param), C.c_int, C.POINTER(ProposalCfg), C.POINTER(vp)]),
+    "fd_detector_destroy": (None, [vp]),
+    "fd_detector_set_proposal": (C.c_int, [vp, C.POINTER(ProposalCfg)]),
+    "fd_forward": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_float, vp, vp, vp, vp]),
+    "fd_detect": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_int, vp, vp, vp, vp]),
+    "fd_detector_keep_tensors": (C.c_int, [vp, C.c_int]),
+    "fd_detector_tensor": (C.c_int, [vp, C.c_char_p, vp, C.c_int64, C.POINTER(C.c_int64), vp]),
 }
 
 _lock = threading.Lock()

@@ -1,0 +1,423 @@
+// fp32 implicit-GEMM convolution on the gfx950 matrix cores (v_mfma_f32_32x32x2_f32) and
+// the small layers around it.
+//
+// GEMM view of a convolution:  Y[m][n] = sum_k A[m][k] * Wt[n][k]
+//   m = output pixel (image, ho, wo), n = output channel, k = (kh, kw, cin) tap-major.
+// A is never materialised: each thread gathers 16-byte channel runs of the NHWC input for
+// its rows of the tile (zero for padding taps), optionally applies the preceding
+// BatchNorm+ReLU on the fly, and stages them in LDS.  A 256-thread workgroup (4 waves, 2x2)
+// owns a BM x BN output tile; each wave accumulates (BM/2)x(BN/2) in 32x32 MFMA tiles.
+//
+// LDS rows hold BK = 32 floats padded to 36, so the 16-byte fragment reads of 32 consecutive
+// rows fall on distinct banks.  Within an 8-deep k-group lane-half h reads floats 4h..4h+3
+// of its row; MFMA step t therefore multiplies k = t (lanes 0-31) and k = 4 + t (lanes
+// 32-63) -- the same permutation of k for both operands, which a sum over k does not mind.
+//
+// Pipeline: global loads of K-step t+1 are issued into registers before the MFMAs of step
+// t and written to the other LDS buffer after them; one barrier per K-step.
+#include "fd_conv.h"
+
+#include <cfloat>
+
+namespace fd {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct ConvKArgs {
+    const float* x;
+    const float* w;
+    const float* bias;
+    const float* pre_scale;
+    const float* pre_shift;
+    const float* res;
+    float* y;
+    int H, W, Cin, Ho, Wo, Cout, KW, stride, pad, K, M, relu, tiles_n;
+};
+
+constexpr int BK = 32;
+constexpr int LDK = 36;
+
+template <int BM, int BN, bool C4>
+__global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvKArgs a) {
+    constexpr int RA = BM / 32, RB = BN / 32;   // 16-byte loads per thread per K-step
+    constexpr int MT = BM / 64, NT = BN / 64;   // 32x32 accumulator tiles per wave
+    __shared__ __attribute__((aligned(16))) float As[2][BM * LDK];
+    __shared__ __attribute__((aligned(16))) float Bs[2][BN * LDK];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+
+    // Workgroups sharing an XCD (ids equal mod 8) take a contiguous run of tiles, so the
+    // activation rows they re-read stay in that XCD's L2.
+    int wgid;
+    {
+        const int nwg = gridDim.x, bid = blockIdx.x;
+        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+        wgid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    }
+    const int tile_n = wgid % a.tiles_n, tile_m = wgid / a.tiles_n;
+
+    const int c4 = tid & 7, r0 = tid >> 3;
+    int hi0[RA], wi0[RA];
+    size_t abase[RA];
+    bool mval[RA];
+#pragma unroll
+    for (int i = 0; i < RA; ++i) {
+        const int m = tile_m * BM + r0 + 32 * i;
+        mval[i] = m < a.M;
+        const int mm = mval[i] ? m : 0;
+        const int hw = a.Ho * a.Wo;
+        const int img = mm / hw;
+        const int rem = mm - img * hw;
+        const int ho = rem / a.Wo;
+        const int wo = rem - ho * a.Wo;
+        hi0[i] = ho * a.stride - a.pad;
+        wi0[i] = wo * a.stride - a.pad;
+        abase[i] = (size_t)img * a.H * a.W * a.Cin;
+    }
+    const float* wrow[RB];
+#pragma unroll
+    for (int i = 0; i < RB; ++i) wrow[i] = a.w + (size_t)(tile_n * BN + r0 + 32 * i) * a.K + c4 * 4;
+
+    float4 ra[RA], rb[RB];
+    int kh = 0, kw = 0, coff = 0;   // tap and channel offset of the K-step being loaded
+    int kt_load = 0;
+
+    auto gload = [&]() {
+        int th, tw, tc;
+        if (C4) { th = kt_load; tw = c4; tc = 0; }
+        else    { th = kh; tw = kw; tc = coff + c4 * 4; }
+        float4 s4 = make_float4(1.f, 1.f, 1.f, 1.f), t4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (a.pre_scale) {
+            s4 = *reinterpret_cast<const float4*>(a.pre_scale + tc);
+            t4 = *reinterpret_cast<const float4*>(a.pre_shift + tc);
+        }
+#pragma unroll
+        for (int i = 0; i < RA; ++i) {
+            const int hi = hi0[i] + th, wi = wi0[i] + tw;
+            const bool ok = mval[i] && (unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (ok) {
+                v = *reinterpret_cast<const float4*>(a.x + abase[i] + ((size_t)hi * a.W + wi) * a.Cin + tc);
+                if (a.pre_scale) {
+                    v.x = fmaxf(v.x * s4.x + t4.x, 0.f);
+                    v.y = fmaxf(v.y * s4.y + t4.y, 0.f);
+                    v.z = fmaxf(v.z * s4.z + t4.z, 0.f);
+                    v.w = fmaxf(v.w * s4.w + t4.w, 0.f);
+                }
+            }
+            ra[i] = v;
+        }
+#pragma unroll
+        for (int i = 0; i < RB; ++i) rb[i] = *reinterpret_cast<const float4*>(wrow[i] + (size_t)kt_load * BK);
+        // advance to the next K-step
+        ++kt_load;
+        if (!C4) {
+            coff += BK;
+            if (coff >= a.Cin) {
+                coff = 0;
+                if (++kw == a.KW) { kw = 0; ++kh; }
+            }
+        }
+    };
+    auto lstore = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < RA; ++i) *reinterpret_cast<float4*>(&As[buf][(r0 + 32 * i) * LDK + c4 * 4]) = ra[i];
+#pragma unroll
+        for (int i = 0; i < RB; ++i) *reinterpret_cast<float4*>(&Bs[buf][(r0 + 32 * i) * LDK + c4 * 4]) = rb[i];
+    };
+
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NT; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+
+    const int frow = lane & 31, fcol = (lane >> 5) * 4;
+    auto compute = [&](int buf) {
+        const float* Ab = &As[buf][(wm * (BM / 2) + frow) * LDK + fcol];
+        const float* Bb = &Bs[buf][(wn * (BN / 2) + frow) * LDK + fcol];
+#pragma unroll
+        for (int kg = 0; kg < BK / 8; ++kg) {
+            float4 af[MT], bf[NT];
+#pragma unroll
+            for (int mi = 0; mi < MT; ++mi) af[mi] = *reinterpret_cast<const float4*>(Ab + mi * 32 * LDK + kg * 8);
+#pragma unroll
+            for (int ni = 0; ni < NT; ++ni) bf[ni] = *reinterpret_cast<const float4*>(Bb + ni * 32 * LDK + kg * 8);
+#pragma unroll
+            for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < NT; ++ni) {
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mi].x, bf[ni].x, acc[mi][ni], 0, 0, 0);
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mi].y, bf[ni].y, acc[mi][ni], 0, 0, 0);
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mi].z, bf[ni].z, acc[mi][ni], 0, 0, 0);
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mi].w, bf[ni].w, acc[mi][ni], 0, 0, 0);
+                }
+        }
+    };
+
+    const int nk = a.K / BK;
+    gload();
+    lstore(0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        const bool more = kt + 1 < nk;
+        if (more) gload();
+        compute(cur);
+        if (more) lstore(cur ^ 1);
+        __syncthreads();
+    }
+
+    // epilogue: C/D layout of the 32x32 tile is col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
+#pragma unroll
+    for (int ni = 0; ni < NT; ++ni) {
+        const int col = tile_n * BN + wn * (BN / 2) + ni * 32 + (lane & 31);
+        if (col >= a.Cout) continue;
+        const float b = a.bias ? a.bias[col] : 0.f;
+#pragma unroll
+        for (int mi = 0; mi < MT; ++mi) {
+            const int rbase = tile_m * BM + wm * (BM / 2) + mi * 32 + 4 * (lane >> 5);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = rbase + (r & 3) + 8 * (r >> 2);
+                if (row < a.M) {
+                    float v = acc[mi][ni][r] + b;
+                    if (a.relu) v = fmaxf(v, 0.f);
+                    const size_t o = (size_t)row * a.Cout + col;
+                    if (a.res) v += a.res[o];
+                    a.y[o] = v;
+                }
+            }
+        }
+    }
+}
+
+template <int BM, int BN, bool C4>
+static int launch_conv(const ConvKArgs& a, hipStream_t stream) {
+    ConvKArgs k = a;
+    const int tiles_m = ceil_div(a.M, BM);
+    k.tiles_n = ceil_div(a.Cout, BN);
+    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, C4>), dim3(tiles_m * k.tiles_n), dim3(256), 0, stream, k);
+    FD_LAUNCH_CHECK();
+    return FD_OK;
+}
+
+int conv_forward(const ConvParams& p, const float* x, int batch, int h, int w, const float* residual, float* y,
+                 hipStream_t stream) {
+    const ConvShape& s = p.s;
+    FD_REQUIRE(x && y && p.w, "conv: NULL tensor");
+    FD_REQUIRE(batch > 0 && h > 0 && w > 0, "conv: bad input shape %d x %d x %d", batch, h, w);
+    const bool c4 = (s.cin == 4);
+    FD_REQUIRE(c4 ? (s.kwp == 8) : (s.cin % 32 == 0 && s.kwp == s.kw),
+               "conv: input channels must be a multiple of 32 (or the 4-channel staged image with kwp = 8), got %d",
+               s.cin);
+    FD_REQUIRE(!(p.pre_scale && s.pad != 0), "conv: the fused input BatchNorm is only defined for unpadded convolutions");
+    const int ho = s.out_h(h), wo = s.out_w(w);
+    FD_REQUIRE(ho > 0 && wo > 0, "conv: empty output");
+    const long long m_ll = (long long)batch * ho * wo;
+    FD_REQUIRE(m_ll < (1ll << 31) / 4, "conv: too many output pixels (%lld)", m_ll);
+    ConvKArgs a;
+    a.x = x; a.w = p.w; a.bias = p.bias; a.pre_scale = p.pre_scale; a.pre_shift = p.pre_shift;
+    a.res = residual; a.y = y;
+    a.H = h; a.W = w; a.Cin = s.cin; a.Ho = ho; a.Wo = wo; a.Cout = s.cout; a.KW = s.kwp;
+    a.stride = s.stride; a.pad = s.pad; a.K = s.k(); a.M = (int)m_ll; a.relu = p.relu; a.tiles_n = 0;
+    if (c4) return launch_conv<128, 64, true>(a, stream);
+    // Tile choice: the biggest tile that still gives the 256 CUs about two workgroups each.
+    const long long t128 = (long long)ceil_div(a.M, 128) * ceil_div(s.cout, 128);
+    const long long t12864 = (long long)ceil_div(a.M, 128) * ceil_div(s.cout, 64);
+    if (s.cout > 64 && t128 >= 384) return launch_conv<128, 128, false>(a, stream);
+    if (t12864 >= 384) return launch_conv<128, 64, false>(a, stream);
+    return launch_conv<64, 64, false>(a, stream);
+}
+
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pack_weights_kernel(const float* __restrict__ w, int cout, int cin_w, int kh,
+                                                          int kw, int kwp, int cin_p, int cout_pad,
+                                                          const float* __restrict__ scale, float* __restrict__ out) {
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long total = (long long)cout_pad * kh * kwp * cin_p;
+    if (t >= total) return;
+    const int c = (int)(t % cin_p);
+    const int x = (int)((t / cin_p) % kwp);
+    const int y = (int)((t / ((long long)cin_p * kwp)) % kh);
+    const int o = (int)(t / ((long long)cin_p * kwp * kh));
+    float v = 0.f;
+    if (o < cout && x < kw && c < cin_w) {
+        v = w[(((size_t)o * cin_w + c) * kh + y) * kw + x];
+        if (scale) v *= scale[o];
+    }
+    out[t] = v;
+}
+
+int pack_conv_weights(const float* w_oihw, int cin_w, const ConvShape& s, const float* out_scale, float* packed,
+                      hipStream_t stream) {
+    FD_REQUIRE(w_oihw && packed && cin_w > 0 && cin_w <= s.cin, "pack_conv_weights: bad arguments");
+    const long long total = (long long)s.packed_floats();
+    hipLaunchKernelGGL(pack_weights_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, stream, w_oihw, s.cout, cin_w,
+                       s.kh, s.kw, s.kwp, s.cin, s.cout_pad(), out_scale, packed);
+    FD_LAUNCH_CHECK();
+    return FD_OK;
+}
+
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void maxpool_kernel(const float4* __restrict__ x, int B, int H, int W, int C4n, int Ho,
+                                                     int Wo, float4* __restrict__ y) {
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long total = (long long)B * Ho * Wo * C4n;
+    if (t >= total) return;
+    const int c = (int)(t % C4n);
+    const int wo = (int)((t / C4n) % Wo);
+    const int ho = (int)((t / ((long long)C4n * Wo)) % Ho);
+    const int b = (int)(t / ((long long)C4n * Wo * Ho));
+    float4 m = make_float4(-FLT_MAX, -FLT_MAX, -FLT_MAX, -FLT_MAX);
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy) {
+        const int hi = ho * 2 - 1 + dy;
+        if ((unsigned)hi >= (unsigned)H) continue;
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) {
+            const int wi = wo * 2 - 1 + dx;
+            if ((unsigned)wi >= (unsigned)W) continue;
+            const float4 v = x[(((size_t)b * H + hi) * W + wi) * C4n + c];
+            m.x = fmaxf(m.x, v.x); m.y = fmaxf(m.y, v.y); m.z = fmaxf(m.z, v.z); m.w = fmaxf(m.w, v.w);
+        }
+    }
+    y[t] = m;
+}
+
+int maxpool_3x3s2(const float* x, int batch, int h, int w, int c, float* y, hipStream_t stream) {
+    FD_REQUIRE(x && y && c % 4 == 0, "maxpool: bad arguments");
+    const int ho = (h + 2 - 3) / 2 + 1, wo = (w + 2 - 3) / 2 + 1;
+    const long long total = (long long)batch * ho * wo * (c / 4);
+    hipLaunchKernelGGL(maxpool_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, stream,
+                       reinterpret_cast<const float4*>(x), batch, h, w, c / 4, ho, wo, reinterpret_cast<float4*>(y));
+    FD_LAUNCH_CHECK();
+    return FD_OK;
+}
+
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void stage_input_kernel(const uint8_t* __restrict__ f, long long pixels, InputNorm n,
+                                                         float4* __restrict__ y) {
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= pixels) return;
+    const uint8_t* p = f + t * 3;
+    y[t] = make_float4((float)p[0] * n.scale[0] + n.shift[0], (float)p[1] * n.scale[1] + n.shift[1],
+                       (float)p[2] * n.scale[2] + n.shift[2], 0.f);
+}
+
+int stage_input(const uint8_t* frames, int batch, int h, int w, const InputNorm& norm, float* y, hipStream_t stream) {
+    FD_REQUIRE(frames && y, "stage_input: NULL tensor");
+    const long long pixels = (long long)batch * h * w;
+    hipLaunchKernelGGL(stage_input_kernel, dim3(ceil_div(pixels, 256)), dim3(256), 0, stream, frames, pixels, norm,
+                       reinterpret_cast<float4*>(y));
+    FD_LAUNCH_CHECK();
+    return FD_OK;
+}
+
+// ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void bn_relu_avgpool_kernel(const float4* __restrict__ x, int hw, int C4n,
+                                                             const float4* __restrict__ scale,
+                                                             const float4* __restrict__ shift, float4* __restrict__ y) {
+    const int n = blockIdx.y;
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C4n) return;
+    const float4 s = scale[c], t = shift[c];
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int p = 0; p < hw; ++p) {
+        const float4 v = x[((size_t)n * hw + p) * C4n + c];
+        acc.x += fmaxf(v.x * s.x + t.x, 0.f);
+        acc.y += fmaxf(v.y * s.y + t.y, 0.f);
+        acc.z += fmaxf(v.z * s.z + t.z, 0.f);
+        acc.w += fmaxf(v.w * s.w + t.w, 0.f);
+    }
+    const float inv = 1.0f / (float)hw;
+    y[(size_t)n * C4n + c] = make_float4(acc.x * inv, acc.y * inv, acc.z * inv, acc.w * inv);
+}
+
+int bn_relu_avgpool(const float* x, int n, int hw, int c, const float* scale, const float* shift, float* y,
+                    hipStream_t stream) {
+    FD_REQUIRE(x && y && scale && shift && c % 4 == 0, "bn_relu_avgpool: bad arguments");
+    if (n <= 0) return FD_OK;
+    hipLaunchKernelGGL(bn_relu_avgpool_kernel, dim3(ceil_div(c / 4, 256), n), dim3(256), 0, stream,
+                       reinterpret_cast<const float4*>(x), hw, c / 4, reinterpret_cast<const float4*>(scale),
+                       reinterpret_cast<const float4*>(shift), reinterpret_cast<float4*>(y));
+    FD_LAUNCH_CHECK();
+    return FD_OK;
+}
+
+// ---------------------------------------------------------------------------------
+// One workgroup per roi: 10 dot products of length C, then the 2-way softmax.
+__global__ __launch_bounds__(256) void fc_head_kernel(const float* __restrict__ flat, int C, const float* __restrict__ w_cls,
+                                                     const float* __restrict__ b_cls, const float* __restrict__ w_box,
+                                                     const float* __restrict__ b_box, float* __restrict__ cls_prob,
+                                                     float* __restrict__ bbox) {
+    __shared__ float part[4][10];
+    const int n = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float* f = flat + (size_t)n * C;
+    float acc[10];
+#pragma unroll
+    for (int o = 0; o < 10; ++o) acc[o] = 0.f;
+    for (int c = tid; c < C; c += 256) {
+        const float v = f[c];
+        acc[0] += v * w_cls[c];
+        acc[1] += v * w_cls[C + c];
+#pragma unroll
+        for (int o = 0; o < 8; ++o) acc[2 + o] += v * w_box[(size_t)o * C + c];
+    }
+#pragma unroll
+    for (int o = 0; o < 10; ++o) {
+        float v = acc[o];
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+        if (lane == 0) part[wave][o] = v;
+    }
+    __syncthreads();
+    if (tid < 10) {
+        const float v = part[0][tid] + part[1][tid] + part[2][tid] + part[3][tid];
+        part[0][tid] = v + (tid < 2 ? b_cls[tid] : b_box[tid - 2]);
+    }
+    __syncthreads();
+    if (tid == 0) {
+        const float s0 = part[0][0], s1 = part[0][1];
+        const float m = fmaxf(s0, s1);
+        const float e0 = expf(s0 - m), e1 = expf(s1 - m);
+        cls_prob[(size_t)n * 2 + 0] = e0 / (e0 + e1);
+        cls_prob[(size_t)n * 2 + 1] = e1 / (e0 + e1);
+    }
+    if (tid < 8) bbox[(size_t)n * 8 + tid] = part[0][2 + tid];
+}
+
+int fc_head(const float* flat, int n, int c, const float* w_cls, const float* b_cls, const float* w_box,
+            const float* b_box, float* cls_prob, float* bbox, hipStream_t stream) {
+    FD_REQUIRE(flat && w_cls && b_cls && w_box && b_box && cls_prob && bbox, "fc_head: NULL tensor");
+    if (n <= 0) return FD_OK;
+    hipLaunchKernelGGL(fc_head_kernel, dim3(n), dim3(256), 0, stream, flat, c, w_cls, b_cls, w_box, b_box, cls_prob,
+                       bbox);
+    FD_LAUNCH_CHECK();
+    return FD_OK;
+}
+
+}  // namespace fd
+
+// =================================================================================
+// C ABI: a convolution operator for stage-level parity tests
+// =================================================================================
+extern "C" {
+
+int fd_conv2d(fd_ctx* ctx, const float* x_nhwc, int batch, int height, int width, int cin, const float* w_oihw,
+              int cout, int kh, int kw, int stride, int pad, const float* bias, const float* pre_scale,
+              const float* pre_shift, int relu, const float* residual, float* y_nhwc, void* stream) {
+    FD_REQUIRE(ctx && x_nhwc && w_oihw && y_nhwc, "fd_conv2d: NULL argument");
+    FD_REQUIRE(cin % 32 == 0 && cin > 0 && cout > 0, "fd_conv2d: cin must be a positive multiple of 32 (got %d)", cin);
+    fd::ConvParams p;
+    p.s.cin = cin; p.s.cout = cout; p.s.kh = kh; p.s.kw = kw; p.s.kwp = kw; p.s.stride = stride; p.s.pad = pad;
+    float* packed = nullptr;
+    FD_TRY(fd::scratch_as(ctx, fd::SLOT_MISC0, p.s.packed_floats(), &packed));
+    FD_TRY(fd::pack_conv_weights(w_oihw, cin, p.s, nullptr, packed, fd::as_stream(stream)));
+    p.w = packed; p.bias = bias; p.pre_scale = pre_scale; p.pre_shift = pre_shift; p.relu = relu;
+    return fd::conv_forward(p, x_nhwc, batch, height, width, residual, y_nhwc, fd::as_stream(stream));
+}
+
+}  // extern "C"

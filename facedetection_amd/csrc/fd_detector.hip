@@ -1,0 +1,514 @@
+// The detector: weight preparation (BatchNorm folding, GEMM packing) and the forward pass of
+// faster_rcnn50 (reference: code/detection/symbol/faster_rcnn.py:107-179) as a fixed sequence
+// of kernel launches on one stream.  Nothing in the forward pass synchronises with the host:
+// candidate / keep counts stay on the device and every grid is sized from shape bounds.
+#include "fd_boxes.h"
+#include "fd_conv.h"
+
+#include <cmath>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+namespace fd {
+
+constexpr float BN_EPS = 2e-5f;
+constexpr int UNITS[4] = {3, 4, 6, 3};
+constexpr int FILTERS[5] = {64, 256, 512, 1024, 2048};
+constexpr int POOLED = 7;
+
+struct Unit {
+    ConvParams conv1, conv2, conv3, sc;
+    bool has_sc = false;
+};
+
+struct Tap {
+    std::string name;
+    const float* ptr;
+    int64_t dims[4];
+};
+
+enum NetBuf {
+    NB_STAGED = 0, NB_CONV0, NB_XA, NB_XB, NB_T1, NB_T2, NB_SC, NB_RPN_HID, NB_RPN_OUT, NB_ROIS, NB_ROI_SCORES,
+    NB_POOLED, NB_X4A, NB_X4B, NB_FLAT, NB_CLS, NB_BOX, NB_COUNTS, NB_COUNT
+};
+
+}  // namespace fd
+
+struct fd_detector {
+    fd_ctx* ctx = nullptr;
+    fd_proposal_cfg prop;
+    std::vector<void*> owned;
+    fd::InputNorm norm;
+    fd::ConvParams conv0;
+    std::vector<fd::Unit> stage[4];
+    fd::ConvParams rpn_conv, rpn_out;
+    const float *bn1_scale = nullptr, *bn1_shift = nullptr;
+    const float *w_cls = nullptr, *b_cls = nullptr, *w_box = nullptr, *b_box = nullptr;
+    int32_t* nan_flag = nullptr;
+    std::vector<fd::Tap> taps;
+    fd::Buf net[fd::NB_COUNT];
+    bool keep_taps = false;              // debugging: snapshot every tapped tensor
+    std::vector<void*> tap_copies;
+};
+
+namespace fd {
+
+// ----------------------------------------------------------------------------- weights
+struct ParamTable {
+    std::map<std::string, const fd_param*> m;
+    const fd_param* get(const std::string& name, int64_t numel) const {
+        auto it = m.find(name);
+        if (it == m.end()) {
+            set_error("missing parameter '%s'", name.c_str());
+            return nullptr;
+        }
+        if (it->second->numel != numel || !it->second->data_host) {
+            set_error("parameter '%s' has %lld elements, expected %lld", name.c_str(), (long long)it->second->numel,
+                      (long long)numel);
+            return nullptr;
+        }
+        return it->second;
+    }
+};
+
+static int upload(fd_detector* d, const float* host, size_t n, float** out) {
+    void* p = nullptr;
+    FD_HIP(hipMalloc(&p, n * sizeof(float)));
+    d->owned.push_back(p);
+    FD_HIP(hipMemcpy(p, host, n * sizeof(float), hipMemcpyHostToDevice));
+    *out = static_cast<float*>(p);
+    return FD_OK;
+}
+
+// Inference BatchNorm as y = x * scale + shift:  scale = gamma / sqrt(var + eps), shift = beta - mean * scale.
+static int bn_fold(const ParamTable& t, const std::string& name, int ch, bool fix_gamma, std::vector<float>& scale,
+                   std::vector<float>& shift) {
+    const fd_param* g = t.get(name + "_gamma", ch);
+    const fd_param* b = t.get(name + "_beta", ch);
+    const fd_param* mu = t.get(name + "_moving_mean", ch);
+    const fd_param* var = t.get(name + "_moving_var", ch);
+    if (!g || !b || !mu || !var) return FD_ERR_PARAM;
+    scale.resize(ch);
+    shift.resize(ch);
+    for (int c = 0; c < ch; ++c) {
+        const double s = (fix_gamma ? 1.0 : (double)g->data_host[c]) / std::sqrt((double)var->data_host[c] + (double)BN_EPS);
+        scale[c] = (float)s;
+        shift[c] = (float)((double)b->data_host[c] - (double)mu->data_host[c] * s);
+    }
+    return FD_OK;
+}
+
+// Uploads OIHW weights, packs them for the GEMM (scaled per output channel when out_scale is given).
+static int make_conv(fd_detector* d, const float* w_host, int cin_w, ConvShape s, const std::vector<float>* out_scale,
+                     const std::vector<float>* bias, int relu, ConvParams* out) {
+    float *raw = nullptr, *scale_d = nullptr, *packed = nullptr, *bias_d = nullptr;
+    const size_t nraw = (size_t)s.cout * cin_w * s.kh * s.kw;
+    FD_HIP(hipMalloc((void**)&raw, nraw * sizeof(float)));
+    FD_HIP(hipMemcpy(raw, w_host, nraw * sizeof(float), hipMemcpyHostToDevice));
+    if (out_scale) {
+        FD_HIP(hipMalloc((void**)&scale_d, s.cout * sizeof(float)));
+        FD_HIP(hipMemcpy(scale_d, out_scale->data(), s.cout * sizeof(float), hipMemcpyHostToDevice));
+    }
+    FD_HIP(hipMalloc((void**)&packed, s.packed_floats() * sizeof(float)));
+    d->owned.push_back(packed);
+    FD_TRY(pack_conv_weights(raw, cin_w, s, scale_d, packed, nullptr));
+    FD_HIP(hipDeviceSynchronize());
+    FD_HIP(hipFree(raw));
+    if (scale_d) FD_HIP(hipFree(scale_d));
+    if (bias) FD_TRY(upload(d, bias->data(), bias->size(), &bias_d));
+    out->s = s;
+    out->w = packed;
+    out->bias = bias_d;
+    out->relu = relu;
+    return FD_OK;
+}
+
+static ConvShape shape(int cin, int cout, int k, int stride, int pad) {
+    ConvShape s;
+    s.cin = cin; s.cout = cout; s.kh = k; s.kw = k; s.kwp = k; s.stride = stride; s.pad = pad;
+    return s;
+}
+
+static int build_unit(fd_detector* d, const ParamTable& t, const std::string& name, int cin, int cout, int stride,
+                      bool dim_match, Unit* u) {
+    const int mid = cout / 4;
+    std::vector<float> s1, h1, s2, h2, s3, h3;
+    FD_TRY(bn_fold(t, name + "_bn1", cin, false, s1, h1));
+    FD_TRY(bn_fold(t, name + "_bn2", mid, false, s2, h2));
+    FD_TRY(bn_fold(t, name + "_bn3", mid, false, s3, h3));
+    const fd_param* w1 = t.get(name + "_conv1_weight", (int64_t)mid * cin);
+    const fd_param* w2 = t.get(name + "_conv2_weight", (int64_t)mid * mid * 9);
+    const fd_param* w3 = t.get(name + "_conv3_weight", (int64_t)cout * mid);
+    if (!w1 || !w2 || !w3) return FD_ERR_PARAM;
+    // bn1 + relu run inside conv1's (and the shortcut's) input gather; bn2 / bn3 fold into the
+    // convolution that feeds them: scale into the weights, shift into the bias, relu in the epilogue
+    float *pre_s = nullptr, *pre_h = nullptr;
+    FD_TRY(upload(d, s1.data(), s1.size(), &pre_s));
+    FD_TRY(upload(d, h1.data(), h1.size(), &pre_h));
+    FD_TRY(make_conv(d, w1->data_host, cin, shape(cin, mid, 1, 1, 0), &s2, &h2, 1, &u->conv1));
+    u->conv1.pre_scale = pre_s;
+    u->conv1.pre_shift = pre_h;
+    FD_TRY(make_conv(d, w2->data_host, mid, shape(mid, mid, 3, stride, 1), &s3, &h3, 1, &u->conv2));
+    FD_TRY(make_conv(d, w3->data_host, mid, shape(mid, cout, 1, 1, 0), nullptr, nullptr, 0, &u->conv3));
+    u->has_sc = !dim_match;
+    if (u->has_sc) {
+        const fd_param* ws = t.get(name + "_sc_weight", (int64_t)cout * cin);
+        if (!ws) return FD_ERR_PARAM;
+        FD_TRY(make_conv(d, ws->data_host, cin, shape(cin, cout, 1, stride, 0), nullptr, nullptr, 0, &u->sc));
+        u->sc.pre_scale = pre_s;
+        u->sc.pre_shift = pre_h;
+    }
+    return FD_OK;
+}
+
+static int build(fd_detector* d, const ParamTable& t) {
+    std::vector<float> sc, sh;
+    // bn_data (gamma fixed to 1) is applied while the uint8 frame is widened to float
+    FD_TRY(bn_fold(t, "bn_data", 3, true, sc, sh));
+    for (int c = 0; c < 3; ++c) { d->norm.scale[c] = sc[c]; d->norm.shift[c] = sh[c]; }
+    // conv0 7x7/2 on the 4-channel staged image, kernel width padded to 8; bn0 + relu folded in
+    FD_TRY(bn_fold(t, "bn0", FILTERS[0], false, sc, sh));
+    const fd_param* w0 = t.get("conv0_weight", (int64_t)FILTERS[0] * 3 * 49);
+    if (!w0) return FD_ERR_PARAM;
+    ConvShape s0 = shape(4, FILTERS[0], 7, 2, 3);
+    s0.kwp = 8;
+    FD_TRY(make_conv(d, w0->data_host, 3, s0, &sc, &sh, 1, &d->conv0));
+    int cin = FILTERS[0];
+    for (int s = 0; s < 4; ++s) {
+        const int cout = FILTERS[s + 1];
+        d->stage[s].resize(UNITS[s]);
+        for (int u = 0; u < UNITS[s]; ++u) {
+            char name[64];
+            snprintf(name, sizeof(name), "stage%d_unit%d", s + 1, u + 1);
+            FD_TRY(build_unit(d, t, name, cin, cout, (u == 0 && s > 0) ? 2 : 1, u != 0, &d->stage[s][u]));
+            cin = cout;
+        }
+    }
+    // RPN: 3x3 conv + relu, then the two 1x1 heads fused into one 72-row GEMM (24 scores | 48 deltas)
+    {
+        const fd_param* w = t.get("rpn_conv_3x3_weight", 512ll * 1024 * 9);
+        const fd_param* b = t.get("rpn_conv_3x3_bias", 512);
+        if (!w || !b) return FD_ERR_PARAM;
+        std::vector<float> bias(b->data_host, b->data_host + 512);
+        FD_TRY(make_conv(d, w->data_host, 1024, shape(1024, 512, 3, 1, 1), nullptr, &bias, 1, &d->rpn_conv));
+        const int A = d->prop.num_ratios * d->prop.num_scales;
+        const fd_param* wc = t.get("rpn_cls_score_weight", 2ll * A * 512);
+        const fd_param* bc = t.get("rpn_cls_score_bias", 2 * A);
+        const fd_param* wb = t.get("rpn_bbox_pred_weight", 4ll * A * 512);
+        const fd_param* bb = t.get("rpn_bbox_pred_bias", 4 * A);
+        if (!wc || !bc || !wb || !bb) return FD_ERR_PARAM;
+        std::vector<float> wcat(6ull * A * 512), bcat(6 * A);
+        memcpy(wcat.data(), wc->data_host, sizeof(float) * 2 * A * 512);
+        memcpy(wcat.data() + 2ull * A * 512, wb->data_host, sizeof(float) * 4 * A * 512);
+        memcpy(bcat.data(), bc->data_host, sizeof(float) * 2 * A);
+        memcpy(bcat.data() + 2 * A, bb->data_host, sizeof(float) * 4 * A);
+        FD_TRY(make_conv(d, wcat.data(), 512, shape(512, 6 * A, 1, 1, 0), nullptr, &bcat, 0, &d->rpn_out));
+    }
+    // head: bn1 + relu + global average, then the two FullyConnected layers
+    FD_TRY(bn_fold(t, "bn1", FILTERS[4], false, sc, sh));
+    float* p = nullptr;
+    FD_TRY(upload(d, sc.data(), sc.size(), &p)); d->bn1_scale = p;
+    FD_TRY(upload(d, sh.data(), sh.size(), &p)); d->bn1_shift = p;
+    const fd_param* wcls = t.get("cls_score_weight", 2ll * FILTERS[4]);
+    const fd_param* bcls = t.get("cls_score_bias", 2);
+    const fd_param* wbox = t.get("bbox_pred_weight", 8ll * FILTERS[4]);
+    const fd_param* bbox = t.get("bbox_pred_bias", 8);
+    if (!wcls || !bcls || !wbox || !bbox) return FD_ERR_PARAM;
+    FD_TRY(upload(d, wcls->data_host, 2 * FILTERS[4], &p)); d->w_cls = p;
+    FD_TRY(upload(d, bcls->data_host, 2, &p)); d->b_cls = p;
+    FD_TRY(upload(d, wbox->data_host, 8 * FILTERS[4], &p)); d->w_box = p;
+    FD_TRY(upload(d, bbox->data_host, 8, &p)); d->b_box = p;
+    void* flag = nullptr;
+    FD_HIP(hipMalloc(&flag, 256));
+    FD_HIP(hipMemset(flag, 0, 256));
+    d->owned.push_back(flag);
+    d->nan_flag = static_cast<int32_t*>(flag);
+    return FD_OK;
+}
+
+// ----------------------------------------------------------------------------- forward
+struct Plan {
+    fd_detector* d;
+    bool dry;
+    size_t need[NB_COUNT];
+    hipStream_t stream;
+
+    float* buf(NetBuf id, size_t nfloats) {
+        if (dry) {
+            if (nfloats > need[id]) need[id] = nfloats;
+            return nullptr;
+        }
+        return static_cast<float*>(d->net[id].ptr);
+    }
+    void tap(const char* name, const float* p, int64_t a, int64_t b, int64_t c, int64_t e) {
+        if (dry) return;
+        if (d->keep_taps) {
+            // activation buffers are recycled between layers; keep a private copy of this one
+            void* copy = nullptr;
+            const size_t bytes = (size_t)(a * b * c * e) * sizeof(float);
+            if (hipMalloc(&copy, bytes) == hipSuccess) {
+                (void)hipMemcpyAsync(copy, p, bytes, hipMemcpyDeviceToDevice, stream);
+                d->tap_copies.push_back(copy);
+                p = static_cast<const float*>(copy);
+            }
+        }
+        Tap t;
+        t.name = name; t.ptr = p; t.dims[0] = a; t.dims[1] = b; t.dims[2] = c; t.dims[3] = e;
+        d->taps.push_back(t);
+    }
+};
+
+static int run_unit(Plan& pl, const Unit& u, const char* name, const float* x, int n, int h, int w, float* y,
+                    int* ho_out, int* wo_out) {
+    const int mid = u.conv1.s.cout, cout = u.conv3.s.cout;
+    const int ho = u.conv2.s.out_h(h), wo = u.conv2.s.out_w(w);
+    float* t1 = pl.buf(NB_T1, (size_t)n * h * w * mid);
+    float* t2 = pl.buf(NB_T2, (size_t)n * ho * wo * mid);
+    const float* res = x;
+    if (u.has_sc) {
+        float* s = pl.buf(NB_SC, (size_t)n * ho * wo * cout);
+        if (!pl.dry) FD_TRY(conv_forward(u.sc, x, n, h, w, nullptr, s, pl.stream));
+        res = s;
+    }
+    if (!pl.dry) {
+        FD_TRY(conv_forward(u.conv1, x, n, h, w, nullptr, t1, pl.stream));
+        FD_TRY(conv_forward(u.conv2, t1, n, h, w, nullptr, t2, pl.stream));
+        FD_TRY(conv_forward(u.conv3, t2, n, ho, wo, res, y, pl.stream));
+    }
+    pl.tap(name, y, n, ho, wo, cout);
+    *ho_out = ho;
+    *wo_out = wo;
+    return FD_OK;
+}
+
+// frames: uint8 [B][H][W][3].  Outputs (device, may be NULL to keep them internal):
+// rois [B*R][5], cls_prob [B*R][2], bbox [B*R][8].
+static int run_graph(Plan& pl, const uint8_t* frames, int B, int H, int W, float im_scale, float** rois_io,
+                     float** cls_io, float** box_io) {
+    fd_detector* d = pl.d;
+    const int R = d->prop.post_nms_top_n;
+    float* staged = pl.buf(NB_STAGED, (size_t)B * H * W * 4);
+    if (!pl.dry) FD_TRY(stage_input(frames, B, H, W, d->norm, staged, pl.stream));
+    const int h1 = d->conv0.s.out_h(H), w1 = d->conv0.s.out_w(W);
+    float* c0 = pl.buf(NB_CONV0, (size_t)B * h1 * w1 * FILTERS[0]);
+    if (!pl.dry) FD_TRY(conv_forward(d->conv0, staged, B, H, W, nullptr, c0, pl.stream));
+    pl.tap("conv0", c0, B, h1, w1, FILTERS[0]);
+    int h = (h1 + 2 - 3) / 2 + 1, w = (w1 + 2 - 3) / 2 + 1;
+    // ping-pong activations; sized for the widest stage
+    size_t xmax = (size_t)B * h * w * FILTERS[0];
+    {
+        int hh = h, ww = w;
+        for (int s = 0; s < 3; ++s) {
+            if (s > 0) { hh = (hh + 2 - 3) / 2 + 1; ww = (ww + 2 - 3) / 2 + 1; }
+            const size_t v = (size_t)B * hh * ww * FILTERS[s + 1];
+            if (v > xmax) xmax = v;
+        }
+    }
+    float* xa = pl.buf(NB_XA, xmax);
+    float* xb = pl.buf(NB_XB, xmax);
+    if (!pl.dry) FD_TRY(maxpool_3x3s2(c0, B, h1, w1, FILTERS[0], xa, pl.stream));
+    pl.tap("pool0", xa, B, h, w, FILTERS[0]);
+    float *cur = xa, *nxt = xb;
+    for (int s = 0; s < 3; ++s)
+        for (size_t u = 0; u < d->stage[s].size(); ++u) {
+            char name[32];
+            snprintf(name, sizeof(name), "stage%d_unit%d", s + 1, (int)u + 1);
+            FD_TRY(run_unit(pl, d->stage[s][u], name, cur, B, h, w, nxt, &h, &w));
+            float* t = cur; cur = nxt; nxt = t;
+        }
+    const float* feat = cur;
+    pl.tap("feat", feat, B, h, w, FILTERS[3]);
+    const int fh = h, fw = w;
+    const int A = d->prop.num_ratios * d->prop.num_scales;
+    float* hid = pl.buf(NB_RPN_HID, (size_t)B * fh * fw * 512);
+    float* rout = pl.buf(NB_RPN_OUT, (size_t)B * fh * fw * 6 * A);
+    if (!pl.dry) {
+        FD_TRY(conv_forward(d->rpn_conv, feat, B, fh, fw, nullptr, hid, pl.stream));
+        FD_TRY(conv_forward(d->rpn_out, hid, B, fh, fw, nullptr, rout, pl.stream));
+    }
+    pl.tap("rpn_out", rout, B, fh, fw, 6 * A);
+    float* rois = pl.buf(NB_ROIS, (size_t)B * R * 5);
+    float* roi_scores = pl.buf(NB_ROI_SCORES, (size_t)B * R);
+    int32_t* counts = reinterpret_cast<int32_t*>(pl.buf(NB_COUNTS, (size_t)B * 4));
+    if (!pl.dry) {
+        if (rois_io && *rois_io) rois = *rois_io;
+        RpnLayout lay;   // channels-last fused head: [pixel][bg(A) | fg(A) | deltas(4A)]
+        lay.cls_batch = (long long)fh * fw * 6 * A; lay.cls_anchor = 1; lay.cls_h = (long long)fw * 6 * A;
+        lay.cls_w = 6 * A; lay.cls_bg_off = 0; lay.cls_fg_off = A;
+        lay.box_batch = lay.cls_batch; lay.box_chan = 1; lay.box_h = lay.cls_h; lay.box_w = lay.cls_w;
+        lay.box_off = 2 * A;
+        const float info[3] = {(float)H, (float)W, im_scale};
+        FD_TRY(proposal_run(d->ctx, &d->prop, rout, rout, lay, 1, nullptr, info, B, fh, fw, rois, roi_scores, counts,
+                            d->nan_flag, pl.stream));
+    }
+    pl.tap("rois", rois, B, R, 5, 1);
+    pl.tap("roi_scores", roi_scores, B, R, 1, 1);
+    const int N = B * R;
+    float* pooled = pl.buf(NB_POOLED, (size_t)N * POOLED * POOLED * FILTERS[3]);
+    if (!pl.dry)
+        FD_TRY(roipool_nhwc(feat, B, FILTERS[3], fh, fw, rois, N, POOLED, POOLED, 1.0f / 16.0f, pooled, pl.stream));
+    pl.tap("pooled", pooled, N, POOLED, POOLED, FILTERS[3]);
+    // stage 4 treats every roi as a 7x7 image
+    const size_t x4 = (size_t)N * POOLED * POOLED * FILTERS[4];
+    float* x4a = pl.buf(NB_X4A, x4);
+    float* x4b = pl.buf(NB_X4B, x4);
+    const float* c4 = pooled;
+    float* n4 = x4a;
+    h = POOLED; w = POOLED;
+    for (size_t u = 0; u < d->stage[3].size(); ++u) {
+        char name[32];
+        snprintf(name, sizeof(name), "stage4_unit%d", (int)u + 1);
+        FD_TRY(run_unit(pl, d->stage[3][u], name, c4, N, h, w, n4, &h, &w));
+        c4 = n4;
+        n4 = (n4 == x4a) ? x4b : x4a;
+    }
+    float* flat = pl.buf(NB_FLAT, (size_t)N * FILTERS[4]);
+    float* cls = pl.buf(NB_CLS, (size_t)N * 2);
+    float* box = pl.buf(NB_BOX, (size_t)N * 8);
+    if (!pl.dry) {
+        if (cls_io && *cls_io) cls = *cls_io;
+        if (box_io && *box_io) box = *box_io;
+        FD_TRY(bn_relu_avgpool(c4, N, h * w, FILTERS[4], d->bn1_scale, d->bn1_shift, flat, pl.stream));
+        FD_TRY(fc_head(flat, N, FILTERS[4], d->w_cls, d->b_cls, d->w_box, d->b_box, cls, box, pl.stream));
+        if (rois_io) *rois_io = rois;
+        if (cls_io) *cls_io = cls;
+        if (box_io) *box_io = box;
+    }
+    pl.tap("flat", flat, N, FILTERS[4], 1, 1);
+    pl.tap("cls_prob", cls, N, 2, 1, 1);
+    pl.tap("bbox_pred", box, N, 8, 1, 1);
+    return FD_OK;
+}
+
+static int forward(fd_detector* d, const uint8_t* frames, int B, int H, int W, float im_scale, float** rois,
+                   float** cls, float** box, hipStream_t stream) {
+    FD_REQUIRE(d && frames, "forward: NULL argument");
+    FD_REQUIRE(B > 0 && H >= 32 && W >= 32, "forward: frames must be at least 32x32 (got %d x %d x %d)", B, H, W);
+    FD_REQUIRE(d->prop.post_nms_top_n > 0, "forward: post_nms_top_n must be > 0");
+    FD_HIP(hipSetDevice(d->ctx->device));
+    Plan pl;
+    pl.d = d; pl.stream = stream; pl.dry = true;
+    memset(pl.need, 0, sizeof(pl.need));
+    FD_TRY(run_graph(pl, frames, B, H, W, im_scale, nullptr, nullptr, nullptr));
+    for (int i = 0; i < NB_COUNT; ++i) {
+        Buf& b = d->net[i];
+        const size_t bytes = pl.need[i] * sizeof(float);
+        if (b.cap < bytes) {
+            void* p = nullptr;
+            const size_t want = (bytes + 255) & ~size_t(255);
+            hipError_t e = hipMalloc(&p, want);
+            if (e != hipSuccess) {
+                set_error("activation buffer %d: hipMalloc(%zu) failed: %s", i, want, hipGetErrorString(e));
+                return FD_ERR_HIP;
+            }
+            if (b.ptr) d->ctx->parked.push_back(b.ptr);   // kernels in flight may still read it
+            b.ptr = p;
+            b.cap = want;
+            d->ctx->bytes += (int64_t)want;
+        }
+    }
+    pl.dry = false;
+    d->taps.clear();
+    if (!d->tap_copies.empty()) {
+        FD_HIP(hipStreamSynchronize(stream));
+        for (void* p : d->tap_copies) (void)hipFree(p);
+        d->tap_copies.clear();
+    }
+    return run_graph(pl, frames, B, H, W, im_scale, rois, cls, box);
+}
+
+}  // namespace fd
+
+// =================================================================================
+// C ABI
+// =================================================================================
+extern "C" {
+
+int fd_detector_create(fd_ctx* ctx, const fd_param* params, int n_params, const fd_proposal_cfg* cfg,
+                       fd_detector** out) {
+    FD_REQUIRE(ctx && params && n_params > 0 && cfg && out, "fd_detector_create: bad arguments");
+    FD_REQUIRE(cfg->num_ratios > 0 && cfg->num_scales > 0 && cfg->num_ratios <= 8 && cfg->num_scales <= 8 &&
+                   cfg->num_ratios * cfg->num_scales <= 32,
+               "fd_detector_create: unsupported anchor configuration");
+    FD_HIP(hipSetDevice(ctx->device));
+    fd::ParamTable t;
+    for (int i = 0; i < n_params; ++i)
+        if (params[i].name) t.m[params[i].name] = &params[i];
+    fd_detector* d = new fd_detector();
+    d->ctx = ctx;
+    d->prop = *cfg;
+    const int rc = fd::build(d, t);
+    if (rc != FD_OK) {
+        for (void* p : d->owned) (void)hipFree(p);
+        delete d;
+        return rc;
+    }
+    *out = d;
+    return FD_OK;
+}
+
+void fd_detector_destroy(fd_detector* d) {
+    if (!d) return;
+    (void)hipSetDevice(d->ctx->device);
+    (void)hipDeviceSynchronize();
+    for (void* p : d->owned) (void)hipFree(p);
+    for (void* p : d->tap_copies) (void)hipFree(p);
+    for (auto& b : d->net)
+        if (b.ptr) (void)hipFree(b.ptr);
+    delete d;
+}
+
+int fd_detector_set_proposal(fd_detector* d, const fd_proposal_cfg* cfg) {
+    FD_REQUIRE(d && cfg, "fd_detector_set_proposal: NULL argument");
+    FD_REQUIRE(cfg->num_ratios == d->prop.num_ratios && cfg->num_scales == d->prop.num_scales,
+               "fd_detector_set_proposal: the anchor count is fixed by the weights");
+    FD_REQUIRE(cfg->post_nms_top_n > 0, "fd_detector_set_proposal: post_nms_top_n must be > 0");
+    d->prop = *cfg;
+    return FD_OK;
+}
+
+int fd_detector_keep_tensors(fd_detector* d, int keep) {
+    FD_REQUIRE(d, "fd_detector_keep_tensors: NULL detector");
+    d->keep_taps = keep != 0;
+    return FD_OK;
+}
+
+int fd_forward(fd_detector* d, const uint8_t* frames, int batch, int height, int width, float im_scale, float* rois,
+               float* cls_prob, float* bbox_pred, void* stream) {
+    float *r = rois, *c = cls_prob, *b = bbox_pred;
+    return fd::forward(d, frames, batch, height, width, im_scale, &r, &c, &b, fd::as_stream(stream));
+}
+
+int fd_detect(fd_detector* d, const uint8_t* frames, int batch, int height, int width, float thresh,
+              float nms_thresh, int do_round, float* dets, int32_t* n_dets, int32_t* nan_flag, void* stream) {
+    FD_REQUIRE(d && dets && n_dets, "fd_detect: NULL argument");
+    float *r = nullptr, *c = nullptr, *b = nullptr;
+    hipStream_t s = fd::as_stream(stream);
+    FD_TRY(fd::forward(d, frames, batch, height, width, 1.0f, &r, &c, &b, s));
+    FD_TRY(fd::postprocess_run(d->ctx, r, 5, c, b, batch, d->prop.post_nms_top_n, height, width, thresh, nms_thresh,
+                               do_round, dets, n_dets, s));
+    if (nan_flag) FD_HIP(hipMemcpyAsync(nan_flag, d->nan_flag, sizeof(int32_t), hipMemcpyDeviceToDevice, s));
+    return FD_OK;
+}
+
+int fd_detector_tensor(fd_detector* d, const char* name, float* out, int64_t capacity, int64_t* dims4, void* stream) {
+    FD_REQUIRE(d && name && dims4, "fd_detector_tensor: NULL argument");
+    for (const fd::Tap& t : d->taps) {
+        if (t.name != name) continue;
+        int64_t n = 1;
+        for (int i = 0; i < 4; ++i) { dims4[i] = t.dims[i]; n *= t.dims[i]; }
+        if (out) {
+            FD_REQUIRE(capacity >= n, "fd_detector_tensor: '%s' needs %lld floats, buffer holds %lld", name,
+                       (long long)n, (long long)capacity);
+            FD_HIP(hipMemcpyAsync(out, t.ptr, (size_t)n * sizeof(float), hipMemcpyDeviceToDevice,
+                                  fd::as_stream(stream)));
+        }
+        return FD_OK;
+    }
+    fd::set_error("fd_detector_tensor: no tensor named '%s' in the last forward pass", name);
+    return FD_ERR_ARG;
+}
+
+}  // extern "C"

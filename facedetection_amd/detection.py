@@ -1,0 +1,217 @@
+"""Detector API with the call signature of the reference's code/detection/detection.py.
+
+    det = Detector(model_path, ctx)             # detection.py:26
+    dets = det.detect_face(frame)               # detection.py:33 -> float32 [N,5]
+
+``dets`` rows are (x1, y1, x2, y2, score) in input-image pixels, best score first,
+coordinates rounded to integers -- what the reference hands to its SORT tracker
+(code/tracking/sort.py:185) and to ``Function.stick_boxes`` unchanged.
+
+All arithmetic runs in the HIP library through the C ABI; torch tensors are only
+device buffers.  ``model_path`` may be
+  * a dict ``name -> float32 array`` with MXNet parameter names (arg + aux params),
+  * the path of an ``.npz`` file holding such a dict,
+  * an MXNet checkpoint prefix (``prefix-%04d.params``), read by ``checkpoint.load_params``,
+  * ``"synthetic"`` / ``"synthetic:<seed>"`` for the seeded random-weight model used in
+    tests and benchmarks (the reference's real weights are not redistributable here).
+"""
+import ctypes as C
+import os
+
+import numpy as np
+import torch
+
+from . import _lib, ops, runtime
+from .symbol.config import config
+
+
+def _device_of(ctx):
+    """GPU index from an int, a torch device / string, or an MXNet-style context object."""
+    if ctx is None:
+        return runtime.device_index(None)
+    if hasattr(ctx, "device_id"):
+        return int(ctx.device_id)
+    return runtime.device_index(ctx)
+
+
+def load_model(model_path, epoch=0):
+    if isinstance(model_path, dict):
+        return model_path
+    if isinstance(model_path, str) and model_path.startswith("synthetic"):
+        from .synthetic import synthetic_params
+        seed = int(model_path.split(":", 1)[1]) if ":" in model_path else 0
+        return synthetic_params(seed)
+    if isinstance(model_path, str) and model_path.endswith(".npz"):
+        with np.load(model_path) as z:
+            return {k: z[k] for k in z.files}
+    from .checkpoint import load_params
+    return load_params("%s-%04d.params" % (model_path, epoch))
+
+
+class Detector:
+    """Faster R-CNN face detector (ResNet-50 backbone) on one MI355X."""
+
+    def __init__(self, model_path, ctx=None, epoch=0, box_f64=True):
+        config.TEST.RPN_MIN_SIZE = 50            # detection.py:27
+        self.device = _device_of(ctx)
+        self.ctx = ctx
+        self._box_f64 = box_f64
+        params = load_model(model_path, epoch)
+        self._lib = _lib.lib()
+        with torch.cuda.device(self.device):
+            self._rt = runtime.context(self.device)
+            # the parameter arrays must stay alive and contiguous during the call only
+            keep = []
+            arr = (_lib.Param * len(params))()
+            for i, (name, value) in enumerate(params.items()):
+                a = np.ascontiguousarray(np.asarray(value), dtype=np.float32)
+                keep.append(a)
+                arr[i].name = name.encode("ascii")
+                arr[i].data_host = a.ctypes.data
+                arr[i].numel = a.size
+            self._cfg = self._proposal_cfg()
+            handle = C.c_void_p()
+            _lib.check(self._lib.fd_detector_create(self._rt.handle, arr, len(params), C.byref(self._cfg),
+                                                    C.byref(handle)))
+            self._h = handle
+
+    def _proposal_cfg(self):
+        # values are read from the global config when the detector is built or re-configured,
+        # like the reference bakes them into its symbol (symbol/faster_rcnn.py:98-102)
+        return ops.make_proposal_cfg(feature_stride=16, scales=(4, 8, 16, 32), ratios=(0.5, 1, 2),
+                                     box_f64=self._box_f64)
+
+    def reconfigure(self):
+        """Re-read config.TEST.RPN_* (after the caller changed them)."""
+        self._cfg = self._proposal_cfg()
+        _lib.check(self._lib.fd_detector_set_proposal(self._h, C.byref(self._cfg)))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.fd_detector_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------ helpers
+    def _frames(self, img):
+        """uint8 device tensor [B,H,W,3] from one HWC image or a batch of them."""
+        if isinstance(img, torch.Tensor):
+            t = img
+            if t.dtype != torch.uint8:
+                raise TypeError("frames must be uint8")
+            if t.dim() == 3:
+                t = t.unsqueeze(0)
+            return t.to("cuda:%d" % self.device).contiguous()
+        a = np.asarray(img)
+        if a.ndim == 3:
+            a = a[None]
+        if a.ndim != 4 or a.shape[3] != 3:
+            raise ValueError("expected an image [H,W,3] or a batch [B,H,W,3]")
+        if a.dtype != np.uint8:
+            b = a.astype(np.uint8)
+            if not np.array_equal(b, a):
+                raise TypeError("frames must hold uint8 pixel values")
+            a = b
+        return torch.from_numpy(np.ascontiguousarray(a)).to("cuda:%d" % self.device)
+
+    @property
+    def rois_per_image(self):
+        return int(self._cfg.post_nms_top_n)
+
+    # ------------------------------------------------------------------ API
+    def forward(self, img, im_scale=1.0):
+        """The graph's three outputs (detection.py:44-46) as NumPy arrays:
+        rois [B*R,5], cls_prob [B*R,2], bbox_pred [B*R,8]."""
+        with torch.cuda.device(self.device):
+            f = self._frames(img)
+            B, H, W, _ = f.shape
+            R = self.rois_per_image
+            rois = runtime.empty((B * R, 5), torch.float32, self.device)
+            cls = runtime.empty((B * R, 2), torch.float32, self.device)
+            box = runtime.empty((B * R, 8), torch.float32, self.device)
+            _lib.check(self._lib.fd_forward(self._h, runtime.ptr(f), B, H, W, float(im_scale), runtime.ptr(rois),
+                                            runtime.ptr(cls), runtime.ptr(box), runtime.stream_ptr(self.device)))
+            return rois.cpu().numpy(), cls.cpu().numpy(), box.cpu().numpy()
+
+    def detect_batch_device(self, frames, nms_thresh=0.3, thresh=0.8, do_round=True):
+        """Asynchronous batched detection: frames uint8 [B,H,W,3] already on the GPU.
+        Returns device tensors (dets [B,R,5], n_dets [B], nan_flag [1]); no host sync."""
+        B, H, W, _ = frames.shape
+        R = self.rois_per_image
+        dets = runtime.empty((B, R, 5), torch.float32, self.device)
+        n = runtime.empty((B,), torch.int32, self.device)
+        flag = runtime.empty((1,), torch.int32, self.device)
+        _lib.check(self._lib.fd_detect(self._h, runtime.ptr(frames), B, H, W, float(thresh), float(nms_thresh),
+                                       1 if do_round else 0, runtime.ptr(dets), runtime.ptr(n), runtime.ptr(flag),
+                                       runtime.stream_ptr(self.device)))
+        return dets, n, flag
+
+    def detect_batch(self, frames, nms_thresh=0.3, thresh=0.8, do_round=True):
+        """List of float32 [n_i,5] arrays, one per frame of a same-size batch."""
+        with torch.cuda.device(self.device):
+            f = self._frames(frames)
+            dets, n, flag = self.detect_batch_device(f, nms_thresh, thresh, do_round)
+            n_host = n.cpu().numpy()
+            if int(flag.item()) != 0:
+                raise ValueError("there is nan in input scores or bbox_deltas")
+            dets_host = dets.cpu().numpy()
+            return [dets_host[b, :n_host[b]].copy() for b in range(f.shape[0])]
+
+    def detect_face(self, img_np, nms_thresh=0.3, thresh=0.8):
+        """detection.py:33-60: one HWC uint8 frame -> float32 [N,5]."""
+        return self.detect_batch(img_np, nms_thresh, thresh, True)[0]
+
+    def detect(self, img_np, nms_thresh=0.3, thresh=0.8):
+        """(boxes_and_scores [N,5], landmarks [N,0]).  The reference model predicts no
+        landmarks, so the second array is always empty; it is there for callers that
+        expect a boxes/scores/landmarks triple."""
+        dets = self.detect_face(img_np, nms_thresh, thresh)
+        return dets, np.zeros((dets.shape[0], 0), dtype=np.float32)
+
+    def keep_tensors(self, keep=True):
+        """Debugging: make later forward passes snapshot every named intermediate tensor."""
+        _lib.check(self._lib.fd_detector_keep_tensors(self._h, 1 if keep else 0))
+
+    def tensor(self, name):
+        """An intermediate tensor of the last forward pass as a NumPy array (channels-last)."""
+        with torch.cuda.device(self.device):
+            dims = (C.c_int64 * 4)()
+            _lib.check(self._lib.fd_detector_tensor(self._h, name.encode("ascii"), None, 0, dims, None))
+            shape = tuple(int(v) for v in dims)
+            out = runtime.empty(shape, torch.float32, self.device)
+            _lib.check(self._lib.fd_detector_tensor(self._h, name.encode("ascii"), runtime.ptr(out), out.numel(),
+                                                    dims, runtime.stream_ptr(self.device)))
+            return out.cpu().numpy()
+
+
+def resize(im, target_size, max_size):
+    """Scale the short side to ``target_size`` unless that makes the long side exceed
+    ``max_size`` (detection.py:63-78).  Returns (resized image, scale); the bilinear
+    resampling runs on the GPU with OpenCV's INTER_LINEAR fixed-point arithmetic."""
+    im_size_min = min(im.shape[0], im.shape[1])
+    im_size_max = max(im.shape[0], im.shape[1])
+    im_scale = float(target_size) / float(im_size_min)
+    if np.round(im_scale * im_size_max) > max_size:
+        im_scale = float(max_size) / float(im_size_max)
+    return ops.resize_bilinear(im, im_scale, im_scale), im_scale
+
+
+def init_detector(prefix="detection/mxnet-face-fr50", epoch=0, gpu=0):
+    """detection.py:81-88.  The reference returns (arg_params, aux_params, sym, ctx) for its
+    free-function callers; here the parameters live inside the returned Detector, which
+    stands in for ``sym`` (min-size 24 like the reference's initialiser)."""
+    det = Detector(prefix, gpu, epoch)
+    config.TEST.RPN_MIN_SIZE = 24
+    det.reconfigure()
+    return None, None, det, gpu
+
+
+def detect_face(ctx, sym, arg_params, aux_params, img_nd, nms_thresh=0.3, thresh=0.8):
+    """Free-function form used by older callers in the reference
+    (data_processing/ProcessVideo.py:61, CelebA.py:164): ``sym`` is the Detector from init_detector."""
+    return sym.detect_face(img_nd, nms_thresh=nms_thresh, thresh=thresh)

@@ -105,3 +105,25 @@ def postprocess(rois, scores, bbox_deltas, im_shape, thresh=0.8, nms_thresh=0.3,
     k = int(n.item())
     out = dets[:k]
     return out.cpu().numpy() if as_np else out
+
+
+def conv2d(x, weight, stride=1, pad=0, bias=None, pre_scale=None, pre_shift=None, relu=False, residual=None):
+    """``mx.sym.Convolution`` fused with its neighbours (see fd_conv2d in facedet.h).
+
+    x [B,H,W,Cin] channels-last, weight [Cout,Cin,kh,kw] (MXNet layout); returns y [B,Ho,Wo,Cout].
+    y = relu?(conv(relu(x*pre_scale+pre_shift)?) + bias?) + residual?"""
+    as_np = not isinstance(x, torch.Tensor)
+    B, H, W, Cin = (int(v) for v in x.shape)
+    Cout, Cin_w, kh, kw = (int(v) for v in weight.shape)
+    if Cin_w != Cin:
+        raise ValueError("conv2d: weight expects %d input channels, x has %d" % (Cin_w, Cin))
+    Ho = (H + 2 * pad - kh) // stride + 1
+    Wo = (W + 2 * pad - kw) // stride + 1
+    ctx = runtime.context()
+    dev = lambda a: None if a is None else runtime.to_device(a, torch.float32)
+    xd, wd, bd, sd, hd, rd = dev(x), dev(weight), dev(bias), dev(pre_scale), dev(pre_shift), dev(residual)
+    y = runtime.empty((B, Ho, Wo, Cout), torch.float32)
+    _lib.check(_lib.lib().fd_conv2d(ctx.handle, runtime.ptr(xd), B, H, W, Cin, runtime.ptr(wd), Cout, kh, kw,
+                                    int(stride), int(pad), runtime.ptr(bd), runtime.ptr(sd), runtime.ptr(hd),
+                                    1 if relu else 0, runtime.ptr(rd), runtime.ptr(y), runtime.stream_ptr()))
+    return y.cpu().numpy() if as_np else y

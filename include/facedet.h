@@ -117,6 +117,63 @@ int fd_postprocess(fd_ctx* ctx, const float* rois, const float* scores, const fl
                    int im_h, int im_w, float thresh, float nms_thresh, int do_round, float* dets, int32_t* n_dets,
                    void* stream);
 
+/* Convolution operator ---------------------------------------------------------------
+ * mx.sym.Convolution as used throughout symbol/faster_rcnn.py:33-52,85-89,131, with the
+ * neighbouring BatchNorm / Activation / elementwise-add operators it is fused with here:
+ *   y = [relu]( conv( pre(x) ) + bias ) + residual,   pre(x) = relu(x * pre_scale + pre_shift)
+ * Tensors are channels-last: x [batch, H, W, cin], y / residual [batch, Ho, Wo, cout];
+ * w_oihw [cout, cin, kh, kw] in the reference's (MXNet) weight layout.  bias [cout],
+ * pre_scale / pre_shift [cin] (only for pad == 0) and residual may be NULL.  cin must be
+ * a multiple of 32.  Arithmetic: float32 multiply-accumulate on the matrix cores. */
+int fd_conv2d(fd_ctx* ctx, const float* x_nhwc, int batch, int height, int width, int cin, const float* w_oihw,
+              int cout, int kh, int kw, int stride, int pad, const float* bias, const float* pre_scale,
+              const float* pre_shift, int relu, const float* residual, float* y_nhwc, void* stream);
+
+/* Detector ------------------------------------------------------------------------------
+ * Detector.__init__ (detection.py:26-31): takes the checkpoint's tensors by their MXNet names
+ * (arg_params and aux_params of `mxnet-face-fr50`: conv0_weight, bn0_gamma, bn0_moving_mean,
+ * stage1_unit1_conv1_weight, ..., rpn_conv_3x3_weight/bias, cls_score_weight/bias, ...),
+ * HOST float32 arrays in MXNet layout, and builds faster_rcnn50(num_class=2)
+ * (symbol/faster_rcnn.py:174-179) on the context's GPU.  The arrays are copied; synchronous.
+ * `cfg` carries the config.TEST.RPN_* values that the reference bakes into the graph. */
+typedef struct fd_param {
+    const char* name;
+    const float* data_host;
+    int64_t numel;
+} fd_param;
+
+int fd_detector_create(fd_ctx* ctx, const fd_param* params, int n_params, const fd_proposal_cfg* cfg,
+                       fd_detector** out);
+void fd_detector_destroy(fd_detector* det);
+/* Replaces the proposal settings (the reference mutates `config` and rebuilds the symbol). */
+int fd_detector_set_proposal(fd_detector* det, const fd_proposal_cfg* cfg);
+
+/* exe.forward(is_train=False) (detection.py:42-46): frames uint8 [batch, H, W, 3] (any channel
+ * order: the graph does not care) -> the graph's three outputs, all float32 on the device:
+ * rois [batch*R, 5] (`rpn_rois_output`), cls_prob [batch*R, 2] (`cls_prob_reshape_output`),
+ * bbox_pred [batch*R, 8] (`bbox_pred_reshape_output`), R = post_nms_top_n.  Any of the three
+ * may be NULL.  im_scale is im_info[2] (1 in detect_face, the resize factor in the CLI). */
+int fd_forward(fd_detector* det, const uint8_t* frames, int batch, int height, int width, float im_scale,
+               float* rois, float* cls_prob, float* bbox_pred, void* stream);
+
+/* Detector.detect_face (detection.py:33-60) for `batch` frames of one size: forward pass plus
+ * the tail of fd_postprocess.  dets [batch, R, 5] float32, n_dets [batch] int32: image b has
+ * n_dets[b] valid rows (x1, y1, x2, y2, score), best score first.  *nan_flag (device int32,
+ * may be NULL) is non-zero if the RPN produced a NaN (the reference raises ValueError). */
+int fd_detect(fd_detector* det, const uint8_t* frames, int batch, int height, int width, float thresh,
+              float nms_thresh, int do_round, float* dets, int32_t* n_dets, int32_t* nan_flag, void* stream);
+
+/* Copies an intermediate tensor of the LAST forward pass (channels-last float32) into `out`
+ * (device, `capacity` floats) and writes its 4 dimensions; out == NULL only queries the
+ * dimensions.  Names: conv0, pool0, stage{1..4}_unit{j}, feat, rpn_out, rois, roi_scores,
+ * pooled, flat, cls_prob, bbox_pred.  For parity tests and debugging.  Layer buffers are
+ * recycled inside a pass, so by default only conv0, feat and the tensors after it still hold
+ * their values afterwards; fd_detector_keep_tensors(det, 1) makes later passes snapshot every
+ * named tensor (allocating: debugging only). */
+int fd_detector_keep_tensors(fd_detector* det, int keep);
+int fd_detector_tensor(fd_detector* det, const char* name, float* out, int64_t capacity, int64_t* dims4,
+                       void* stream);
+
 #ifdef __cplusplus
 }
 #endif
