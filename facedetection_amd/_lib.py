@@ -32,6 +32,16 @@ class ProposalCfg(C.Structure):
     ]
 
 
+class ProfileRow(C.Structure):
+    _fields_ = [
+        ("kernel", C.c_char * 64),
+        ("launches", C.c_int64),
+        ("ms", C.c_double),
+        ("flops", C.c_double),
+        ("bytes", C.c_double),
+    ]
+
+
 class Param(C.Structure):
     _fields_ = [
         ("name", C.c_char_p),
@@ -47,6 +57,8 @@ SIGNATURES = {
     "fd_ctx_create": (C.c_int, [C.c_int, C.POINTER(vp)]),
     "fd_ctx_destroy": (None, [vp]),
     "fd_ctx_scratch_bytes": (C.c_int64, [vp]),
+    "fd_profile_begin": (C.c_int, []),
+    "fd_profile_end": (C.c_int, [C.POINTER(ProfileRow), C.c_int, C.POINTER(C.c_int)]),
     "fd_generate_anchors": (C.c_int, [C.c_double, c_f64p, C.c_int, c_f64p, C.c_int, c_f64p]),
     "fd_bbox_pred_f64": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, vp, vp]),
     "fd_clip_boxes_f64": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_double, C.c_double, vp]),
@@ -87,6 +99,10 @@ def lib():
                 raise RuntimeError(
                     "%s is missing: build it with `python -m facedetection_amd._build` "
                     "(there is no CPU fallback)" % LIB_PATH)
+            # torch ships its own HIP runtime; it has to be in the process before this library
+            # so that both resolve to the same libamdhip64 (two runtimes in one process do not
+            # see each other's devices)
+            import torch  # noqa: F401
             handle = C.CDLL(LIB_PATH)
             for name, (res, args) in SIGNATURES.items():
                 fn = getattr(handle, name)     # AttributeError if the symbol is not exported

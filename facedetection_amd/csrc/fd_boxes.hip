@@ -138,6 +138,7 @@ static int sort_pairs(fd_ctx* ctx, K* keys_a, uint32_t* vals_a, K* keys_b, uint3
     uint32_t* hist = nullptr;
     FD_TRY(scratch_as(ctx, SLOT_SORT_HIST, (size_t)nseg * 256 * nblk, &hist));
     dim3 grid(nblk, nseg);
+    ProfScope scope(stream, "radix_sort", 0.0, (double)sizeof(K) * 8 / 8 * 2.0 * (sizeof(K) + 4.0) * n * nseg);
     K* src_k = keys_a;
     uint32_t* src_v = vals_a;
     K* dst_k = keys_b;
@@ -310,12 +311,20 @@ int nms_sorted(fd_ctx* ctx, const T* cand_boxes, int32_t* counters, int cap, int
     uint64_t* mask = nullptr;
     FD_TRY(scratch_as(ctx, SLOT_NMS_MASK, (size_t)nseg * cap * words, &mask));
     dim3 grid(words, words, nseg);
-    hipLaunchKernelGGL(nms_mask_kernel<T>, grid, dim3(64), 0, stream, cand_boxes, counters, cap, words, thresh, mask);
-    FD_LAUNCH_CHECK();
+    {
+        // upper-triangle mask: cap^2/16 bytes written; 4 box coordinates read per candidate
+        ProfScope scope(stream, "nms_mask", 0.0, (double)nseg * ((double)cap * cap / 16.0 + 4.0 * sizeof(T) * cap));
+        hipLaunchKernelGGL(nms_mask_kernel<T>, grid, dim3(64), 0, stream, cand_boxes, counters, cap, words, thresh,
+                           mask);
+        FD_LAUNCH_CHECK();
+    }
     const size_t smem = (size_t)words * 8 + 16;
-    hipLaunchKernelGGL(nms_reduce_kernel, dim3(nseg), dim3(REDUCE_THREADS), smem, stream, mask, counters, cap, words,
-                       max_keep, keep);
-    FD_LAUNCH_CHECK();
+    {
+        ProfScope scope(stream, "nms_reduce", 0.0, (double)nseg * (double)cap * cap / 16.0);
+        hipLaunchKernelGGL(nms_reduce_kernel, dim3(nseg), dim3(REDUCE_THREADS), smem, stream, mask, counters, cap,
+                           words, max_keep, keep);
+        FD_LAUNCH_CHECK();
+    }
     return FD_OK;
 }
 template int nms_sorted<float>(fd_ctx*, const float*, int32_t*, int, int, float, int, int32_t*, hipStream_t);
@@ -513,10 +522,14 @@ static int proposal_run_t(fd_ctx* ctx, const fd_proposal_cfg* cfg, const float* 
     FD_HIP(hipMemsetAsync(counters, 0, sizeof(int32_t) * batch * CNT_STRIDE, stream));
     if (nan_flag) FD_HIP(hipMemsetAsync(nan_flag, 0, sizeof(int32_t), stream));
 
-    hipLaunchKernelGGL(proposal_decode_kernel<T>, dim3(ceil_div(N, 256), batch), dim3(256), 0, stream, cls, bbox, lay,
-                       softmax, anchors, A, H, W, cfg->feat_stride, im_info_dev, info_uniform[0], info_uniform[1],
-                       info_uniform[2], cfg->min_size, boxes, scores, ka, va, counters, nan_flag);
-    FD_LAUNCH_CHECK();
+    {
+        // per anchor: 2 scores + 4 deltas read, box + score + sort pair written
+        ProfScope scope(stream, "proposal_decode", 0.0, (double)batch * N * (24.0 + 4.0 * sizeof(T) + 12.0));
+        hipLaunchKernelGGL(proposal_decode_kernel<T>, dim3(ceil_div(N, 256), batch), dim3(256), 0, stream, cls, bbox,
+                           lay, softmax, anchors, A, H, W, cfg->feat_stride, im_info_dev, info_uniform[0],
+                           info_uniform[1], info_uniform[2], cfg->min_size, boxes, scores, ka, va, counters, nan_flag);
+        FD_LAUNCH_CHECK();
+    }
     FD_TRY(sort_pairs_u32(ctx, ka, va, kb, vb, N, batch, stream));
     hipLaunchKernelGGL(gather_candidates_kernel<T>, dim3(ceil_div(cap, 256), batch), dim3(256), 0, stream, va, boxes,
                        scores, N, cap, counters, cand_boxes, cand_scores, cand_index);
@@ -828,6 +841,7 @@ int roipool_nhwc(const float* data, int batch, int C, int H, int W, const float*
     FD_REQUIRE(data && rois && out, "roipool: NULL argument");
     FD_REQUIRE(C % 4 == 0 && C > 0, "roipool (channels-last): channel count %d must be a multiple of 4", C);
     if (num_rois <= 0) return FD_OK;
+    ProfScope scope(stream, "roipool", 0.0, 2.0 * 4.0 * (double)num_rois * PH * PW * C);
     hipLaunchKernelGGL(roipool_nhwc_kernel, dim3(PH * PW, num_rois), dim3(256), 0, stream, data, batch, C, H, W, rois,
                        num_rois, PH, PW, scale, out);
     FD_LAUNCH_CHECK();

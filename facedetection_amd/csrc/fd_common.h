@@ -100,6 +100,22 @@ inline int scratch_as(fd_ctx* ctx, Slot slot, size_t count, T** out) {
 
 inline hipStream_t as_stream(void* s) { return static_cast<hipStream_t>(s); }
 
+// Optional per-kernel timing with HIP events (fd_profile_begin / fd_profile_end).  A scope
+// records one event before and one after the launches it brackets, on the launch stream,
+// and carries the algorithmic FLOPs / bytes of that work.  Inactive scopes cost one branch.
+bool prof_active();
+int prof_open(hipStream_t stream, const char* kernel, double flops, double bytes);
+void prof_close(hipStream_t stream, int token);
+struct ProfScope {
+    hipStream_t stream;
+    int token;
+    ProfScope(hipStream_t s, const char* kernel, double flops, double bytes)
+        : stream(s), token(prof_active() ? prof_open(s, kernel, flops, bytes) : -1) {}
+    ~ProfScope() {
+        if (token >= 0) prof_close(stream, token);
+    }
+};
+
 inline int ceil_div(long long a, long long b) { return (int)((a + b - 1) / b); }
 
 }  // namespace fd

@@ -18,6 +18,7 @@
 #include "fd_conv.h"
 
 #include <cfloat>
+#include <string>
 
 namespace fd {
 
@@ -197,6 +198,14 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvKArgs a) {
 
 template <int BM, int BN, bool C4>
 static int launch_conv(const ConvKArgs& a, hipStream_t stream) {
+    static const std::string name =
+        std::string("conv_igemm_") + std::to_string(BM) + "x" + std::to_string(BN) + (C4 ? "_stem" : "");
+    // algorithmic work: 2 FLOPs per multiply-add over the real (unpadded) taps; each tensor once
+    const double taps = C4 ? 147.0 : (double)a.K;
+    const double cin_bytes = C4 ? 4.0 * 4 : 4.0 * a.Cin;
+    ProfScope scope(stream, name.c_str(), 2.0 * a.M * a.Cout * taps,
+                    (double)a.H * a.W * (a.M / ((double)a.Ho * a.Wo)) * cin_bytes + 4.0 * a.Cout * taps +
+                        4.0 * a.M * a.Cout * (a.res ? 2.0 : 1.0));
     ConvKArgs k = a;
     const int tiles_m = ceil_div(a.M, BM);
     k.tiles_n = ceil_div(a.Cout, BN);
@@ -292,6 +301,7 @@ int maxpool_3x3s2(const float* x, int batch, int h, int w, int c, float* y, hipS
     FD_REQUIRE(x && y && c % 4 == 0, "maxpool: bad arguments");
     const int ho = (h + 2 - 3) / 2 + 1, wo = (w + 2 - 3) / 2 + 1;
     const long long total = (long long)batch * ho * wo * (c / 4);
+    ProfScope scope(stream, "maxpool_3x3s2", 0.0, 4.0 * c * ((double)batch * h * w + (double)batch * ho * wo));
     hipLaunchKernelGGL(maxpool_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, stream,
                        reinterpret_cast<const float4*>(x), batch, h, w, c / 4, ho, wo, reinterpret_cast<float4*>(y));
     FD_LAUNCH_CHECK();
@@ -311,6 +321,7 @@ __global__ __launch_bounds__(256) void stage_input_kernel(const uint8_t* __restr
 int stage_input(const uint8_t* frames, int batch, int h, int w, const InputNorm& norm, float* y, hipStream_t stream) {
     FD_REQUIRE(frames && y, "stage_input: NULL tensor");
     const long long pixels = (long long)batch * h * w;
+    ProfScope scope(stream, "stage_input", 0.0, 19.0 * (double)pixels);
     hipLaunchKernelGGL(stage_input_kernel, dim3(ceil_div(pixels, 256)), dim3(256), 0, stream, frames, pixels, norm,
                        reinterpret_cast<float4*>(y));
     FD_LAUNCH_CHECK();

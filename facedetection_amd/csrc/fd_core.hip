@@ -5,6 +5,8 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <string>
+#include <vector>
 
 namespace fd {
 
@@ -43,9 +45,93 @@ int scratch(fd_ctx* ctx, Slot slot, size_t bytes, void** out) {
     return FD_OK;
 }
 
+// ---------------------------------------------------------------------------------
+// Event profiler (process-wide; one profiling session at a time).
+struct ProfRec {
+    hipEvent_t a, b;
+    int kernel;
+    double flops, bytes;
+};
+struct Profiler {
+    bool active = false;
+    std::vector<std::string> names;
+    std::vector<ProfRec> recs;
+    std::vector<hipEvent_t> pool;
+};
+static Profiler g_prof;
+
+bool prof_active() { return g_prof.active; }
+
+static hipEvent_t prof_event() {
+    if (!g_prof.pool.empty()) {
+        hipEvent_t e = g_prof.pool.back();
+        g_prof.pool.pop_back();
+        return e;
+    }
+    hipEvent_t e = nullptr;
+    (void)hipEventCreate(&e);
+    return e;
+}
+
+int prof_open(hipStream_t stream, const char* kernel, double flops, double bytes) {
+    int id = -1;
+    for (size_t i = 0; i < g_prof.names.size(); ++i)
+        if (g_prof.names[i] == kernel) id = (int)i;
+    if (id < 0) {
+        g_prof.names.push_back(kernel);
+        id = (int)g_prof.names.size() - 1;
+    }
+    ProfRec r;
+    r.a = prof_event();
+    r.b = prof_event();
+    r.kernel = id;
+    r.flops = flops;
+    r.bytes = bytes;
+    (void)hipEventRecord(r.a, stream);
+    g_prof.recs.push_back(r);
+    return (int)g_prof.recs.size() - 1;
+}
+
+void prof_close(hipStream_t stream, int token) { (void)hipEventRecord(g_prof.recs[token].b, stream); }
+
 }  // namespace fd
 
 extern "C" {
+
+int fd_profile_begin(void) {
+    fd::g_prof.active = true;
+    return FD_OK;
+}
+
+int fd_profile_end(fd_profile_row* rows, int capacity, int* n_rows) {
+    FD_REQUIRE(n_rows, "fd_profile_end: n_rows is NULL");
+    fd::Profiler& P = fd::g_prof;
+    P.active = false;
+    FD_HIP(hipDeviceSynchronize());
+    const int nk = (int)P.names.size();
+    std::vector<fd_profile_row> acc(nk);
+    for (int k = 0; k < nk; ++k) {
+        memset(&acc[k], 0, sizeof(fd_profile_row));
+        snprintf(acc[k].kernel, sizeof(acc[k].kernel), "%s", P.names[k].c_str());
+    }
+    for (fd::ProfRec& r : P.recs) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) {
+            acc[r.kernel].launches += 1;
+            acc[r.kernel].ms += ms;
+            acc[r.kernel].flops += r.flops;
+            acc[r.kernel].bytes += r.bytes;
+        }
+        P.pool.push_back(r.a);
+        P.pool.push_back(r.b);
+    }
+    P.recs.clear();
+    P.names.clear();
+    *n_rows = nk;
+    for (int k = 0; k < nk && k < capacity; ++k)
+        if (rows) rows[k] = acc[k];
+    return FD_OK;
+}
 
 int fd_version(void) { return 100; }
 

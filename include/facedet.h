@@ -42,6 +42,22 @@ void fd_ctx_destroy(fd_ctx* ctx);
 /* Bytes of scratch currently held by the context (diagnostics). */
 int64_t fd_ctx_scratch_bytes(const fd_ctx* ctx);
 
+/* Per-kernel timing with HIP events, for benchmarks (no counterpart in the reference, which
+ * only prints wall time per frame, detection.py:163-164).  Between fd_profile_begin() and
+ * fd_profile_end() every kernel group of the library is bracketed by events on its launch
+ * stream.  fd_profile_end synchronises the device and returns one row per kernel group:
+ * launches, summed event time, and the summed ALGORITHMIC work of those launches (FLOPs with
+ * a multiply-add counted as 2; bytes = each operand tensor read or written once). */
+typedef struct fd_profile_row {
+    char kernel[64];
+    int64_t launches;
+    double ms;
+    double flops;
+    double bytes;
+} fd_profile_row;
+int fd_profile_begin(void);
+int fd_profile_end(fd_profile_row* rows_host, int capacity, int* n_rows);
+
 /* Box arithmetic ------------------------------------------------------------ */
 
 /* generate_anchors(base_size, ratios, scales) -- processing.py:184-248.
