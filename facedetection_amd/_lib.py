@@ -67,6 +67,9 @@ SIGNATURES = {
     "fd_proposal": (C.c_int, [vp, C.POINTER(ProposalCfg), vp, vp, c_f32p, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp]),
     "fd_roipool": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_float, vp, vp]),
     "fd_postprocess": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_int, vp, vp, vp]),
+    "fd_resize_dims": (C.c_int, [C.c_int, C.c_int, C.c_double, C.c_double, c_i32p, c_i32p]),
+    "fd_resize_u8": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, vp, C.c_int,
+                               C.c_int, vp]),
     "fd_conv2d": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                             vp, vp, vp, C.c_int, vp, vp, vp]),
     "fd_detector_create": (C.c_int, [vp, C.POINTER(Param), C.c_int, C.POINTER(ProposalCfg), C.POINTER(vp)]),

@@ -1,0 +1,98 @@
+// Bilinear image resize for uint8 HWC frames, arithmetic-compatible with OpenCV's
+// cv::resize(..., fx, fy, INTER_LINEAR) on 8-bit images (the call at the reference's
+// code/detection/detection.py:77):
+//   * destination size = round-half-even(src size * scale);
+//   * source coordinate of destination column dx: fx = (float)((dx + 0.5) / scale - 0.5),
+//     sx = floor(fx), weight fx - sx; clamped to the first / last source column;
+//   * weights are quantised to 11 bits (x 2048, round half even) and the two passes are
+//     integer:  row value = S[sx] * a0 + S[sx+1] * a1,
+//               out = (((b0 * (R0 >> 4)) >> 16) + ((b1 * (R1 >> 4)) >> 16) + 2) >> 2;
+//   * an exact 2x reduction in both directions averages 2x2 blocks: (a + b + c + d + 2) >> 2.
+// HBM-bound: every source byte is read about once and every destination byte written once.
+// The coordinate arithmetic must round like the host's, so this file is built with
+// floating-point contraction off.
+#include "fd_common.h"
+
+#include <cmath>
+
+#pragma clang fp contract(off)
+
+namespace fd {
+
+struct Tap2 {
+    int s0, s1;      // the two source indices
+    int w0, w1;      // 11-bit weights
+};
+
+__device__ __forceinline__ Tap2 linear_tap(int d, double scale, int ssize) {
+    float f = (float)(((double)d + 0.5) * scale - 0.5);
+    int s = (int)floorf(f);
+    f -= (float)s;
+    if (s < 0) { f = 0.f; s = 0; }
+    if (s >= ssize - 1) { f = 0.f; s = ssize - 1; }
+    Tap2 t;
+    t.s0 = s;
+    t.s1 = min(s + 1, ssize - 1);
+    t.w0 = (int)rintf((1.f - f) * 2048.f);
+    t.w1 = (int)rintf(f * 2048.f);
+    return t;
+}
+
+__global__ __launch_bounds__(256) void resize_linear_u8_kernel(const uint8_t* __restrict__ src, int sh, int sw, int c,
+                                                              double scale_x, double scale_y, uint8_t* __restrict__ dst,
+                                                              int dh, int dw, int area2) {
+    const int dx = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int dy = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const int b = blockIdx.z;
+    if (dx >= dw || dy >= dh) return;
+    const uint8_t* s = src + (size_t)b * sh * sw * c;
+    uint8_t* o = dst + (((size_t)b * dh + dy) * dw + dx) * c;
+    if (area2) {
+        const uint8_t* r0 = s + ((size_t)(2 * dy) * sw + 2 * dx) * c;
+        const uint8_t* r1 = r0 + (size_t)sw * c;
+        for (int k = 0; k < c; ++k) o[k] = (uint8_t)((r0[k] + r0[c + k] + r1[k] + r1[c + k] + 2) >> 2);
+        return;
+    }
+    const Tap2 tx = linear_tap(dx, scale_x, sw);
+    const Tap2 ty = linear_tap(dy, scale_y, sh);
+    const uint8_t* r0 = s + (size_t)ty.s0 * sw * c;
+    const uint8_t* r1 = s + (size_t)ty.s1 * sw * c;
+    for (int k = 0; k < c; ++k) {
+        const int h0 = r0[tx.s0 * c + k] * tx.w0 + r0[tx.s1 * c + k] * tx.w1;
+        const int h1 = r1[tx.s0 * c + k] * tx.w0 + r1[tx.s1 * c + k] * tx.w1;
+        o[k] = (uint8_t)((((ty.w0 * (h0 >> 4)) >> 16) + ((ty.w1 * (h1 >> 4)) >> 16) + 2) >> 2);
+    }
+}
+
+}  // namespace fd
+
+extern "C" {
+
+int fd_resize_dims(int src_h, int src_w, double fx, double fy, int* dst_h, int* dst_w) {
+    FD_REQUIRE(dst_h && dst_w && src_h > 0 && src_w > 0 && fx > 0 && fy > 0, "fd_resize_dims: bad arguments");
+    *dst_w = (int)std::nearbyint((double)src_w * fx);
+    *dst_h = (int)std::nearbyint((double)src_h * fy);
+    FD_REQUIRE(*dst_w > 0 && *dst_h > 0, "fd_resize_dims: empty destination");
+    return FD_OK;
+}
+
+int fd_resize_u8(fd_ctx* ctx, const uint8_t* src, int batch, int src_h, int src_w, int channels, double fx, double fy,
+                 uint8_t* dst, int dst_h, int dst_w, void* stream) {
+    (void)ctx;
+    FD_REQUIRE(src && dst && batch > 0 && channels > 0 && channels <= 4, "fd_resize_u8: bad arguments");
+    int eh = 0, ew = 0;
+    FD_TRY(fd_resize_dims(src_h, src_w, fx, fy, &eh, &ew));
+    FD_REQUIRE(eh == dst_h && ew == dst_w, "fd_resize_u8: destination must be %d x %d for this scale (got %d x %d)", eh,
+               ew, dst_h, dst_w);
+    const double scale_x = 1.0 / fx, scale_y = 1.0 / fy;
+    const int area2 = (scale_x == 2.0 && scale_y == 2.0 && src_w % 2 == 0 && src_h % 2 == 0) ? 1 : 0;
+    fd::ProfScope scope(fd::as_stream(stream), "resize_linear_u8", 0.0,
+                        (double)batch * channels * ((double)src_h * src_w + (double)dst_h * dst_w));
+    dim3 grid(fd::ceil_div(dst_w, 64), fd::ceil_div(dst_h, 4), batch);
+    hipLaunchKernelGGL(fd::resize_linear_u8_kernel, grid, dim3(256), 0, fd::as_stream(stream), src, src_h, src_w,
+                       channels, scale_x, scale_y, dst, dst_h, dst_w, area2);
+    FD_LAUNCH_CHECK();
+    return FD_OK;
+}
+
+}  // extern "C"

@@ -127,3 +127,23 @@ def conv2d(x, weight, stride=1, pad=0, bias=None, pre_scale=None, pre_shift=None
                                     int(stride), int(pad), runtime.ptr(bd), runtime.ptr(sd), runtime.ptr(hd),
                                     1 if relu else 0, runtime.ptr(rd), runtime.ptr(y), runtime.stream_ptr()))
     return y.cpu().numpy() if as_np else y
+
+
+def resize_bilinear(im, fx, fy):
+    """``cv2.resize(im, None, None, fx=fx, fy=fy, interpolation=cv2.INTER_LINEAR)`` for uint8 images
+    [H,W,C] or batches [B,H,W,C] (C <= 4)."""
+    as_np = not isinstance(im, torch.Tensor)
+    single = im.ndim == 3
+    t = runtime.to_device(im, torch.uint8)
+    if single:
+        t = t.unsqueeze(0)
+    B, H, W, Cc = (int(v) for v in t.shape)
+    dh, dw = C.c_int32(0), C.c_int32(0)
+    _lib.check(_lib.lib().fd_resize_dims(H, W, float(fx), float(fy), C.byref(dh), C.byref(dw)))
+    out = runtime.empty((B, dh.value, dw.value, Cc), torch.uint8)
+    ctx = runtime.context()
+    _lib.check(_lib.lib().fd_resize_u8(ctx.handle, runtime.ptr(t), B, H, W, Cc, float(fx), float(fy),
+                                       runtime.ptr(out), dh.value, dw.value, runtime.stream_ptr()))
+    if single:
+        out = out[0]
+    return out.cpu().numpy() if as_np else out

@@ -133,6 +133,15 @@ int fd_postprocess(fd_ctx* ctx, const float* rois, const float* scores, const fl
                    int im_h, int im_w, float thresh, float nms_thresh, int do_round, float* dets, int32_t* n_dets,
                    void* stream);
 
+/* Image resize -----------------------------------------------------------------------
+ * cv2.resize(im, None, None, fx, fy, interpolation=cv2.INTER_LINEAR) on 8-bit images, the call
+ * inside resize() at detection.py:63-78 (OpenCV's fixed-point bilinear arithmetic; see
+ * csrc/fd_image.hip).  src uint8 [batch, src_h, src_w, channels] -> dst uint8
+ * [batch, dst_h, dst_w, channels] with (dst_h, dst_w) as given by fd_resize_dims. */
+int fd_resize_dims(int src_h, int src_w, double fx, double fy, int* dst_h_host, int* dst_w_host);
+int fd_resize_u8(fd_ctx* ctx, const uint8_t* src, int batch, int src_h, int src_w, int channels, double fx,
+                 double fy, uint8_t* dst, int dst_h, int dst_w, void* stream);
+
 /* Convolution operator ---------------------------------------------------------------
  * mx.sym.Convolution as used throughout symbol/faster_rcnn.py:33-52,85-89,131, with the
  * neighbouring BatchNorm / Activation / elementwise-add operators it is fused with here:
