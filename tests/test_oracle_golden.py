@@ -102,3 +102,19 @@ def test_postprocess(golden, R):
     assert dets.dtype == np.float32
     np.testing.assert_array_equal(dets, g[tag + "_dets"])
     np.testing.assert_array_equal(ob.postprocess(*args, do_round=False), g[tag + "_dets_unrounded"])
+
+
+@pytest.mark.parametrize("n", [0, 1, 10, 1000, 6000])
+@pytest.mark.parametrize("thr", [0.3, 0.7])
+def test_c_nms_matches_reference_vectors(golden, n, thr):
+    from oracle import cboxes
+    g = golden("nms")
+    keep = cboxes.nms(g["nms_n%d_dets" % n], thr)
+    np.testing.assert_array_equal(np.asarray(keep, dtype=np.int64), g["nms_n%d_t%d_keep" % (n, int(thr * 10))])
+
+
+def test_c_nms_float64_and_ties(golden):
+    from oracle import cboxes
+    g = golden("nms")
+    np.testing.assert_array_equal(cboxes.nms(g["nms64_dets"], 0.7), g["nms64_t7_keep"])
+    np.testing.assert_array_equal(cboxes.nms(g["nms_tied_dets"], 0.3), ob.nms(g["nms_tied_dets"], 0.3))
