@@ -23,6 +23,7 @@
 namespace fd {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 struct ConvKArgs {
     const float* x;
@@ -59,8 +60,11 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvKArgs a) {
     const int tile_n = wgid % a.tiles_n, tile_m = wgid / a.tiles_n;
 
     const int c4 = tid & 7, r0 = tid >> 3;
-    int hi0[RA], wi0[RA];
-    size_t abase[RA];
+    // Per-row gather state.  A row's input window starts at pixel (hi0, wi0) of its image; the
+    // tap (kh, kw) and channel offset of a K-step are the same for every row, so an address is
+    // xrow[i] + rowoff[i] + (offset of the tap), all in floats relative to the image.
+    int hi0[RA], wi0[RA], rowoff[RA];
+    const float* xrow[RA];
     bool mval[RA];
 #pragma unroll
     for (int i = 0; i < RA; ++i) {
@@ -74,59 +78,68 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvKArgs a) {
         const int wo = rem - ho * a.Wo;
         hi0[i] = ho * a.stride - a.pad;
         wi0[i] = wo * a.stride - a.pad;
-        abase[i] = (size_t)img * a.H * a.W * a.Cin;
+        rowoff[i] = (hi0[i] * a.W + wi0[i]) * a.Cin + c4 * 4;
+        xrow[i] = a.x + (size_t)img * a.H * a.W * a.Cin;
     }
     const float* wrow[RB];
 #pragma unroll
     for (int i = 0; i < RB; ++i) wrow[i] = a.w + (size_t)(tile_n * BN + r0 + 32 * i) * a.K + c4 * 4;
 
-    float4 ra[RA], rb[RB];
-    int kh = 0, kw = 0, coff = 0;   // tap and channel offset of the K-step being loaded
-    int kt_load = 0;
+    // Registers of the K-step in flight: raw input runs, weights, the fused-BatchNorm
+    // coefficients of its channels and which rows hit real pixels.  Loads are unconditional
+    // (padding taps read a harmless in-range address and are zeroed when staged), so they issue
+    // back to back and are only waited for when written to LDS, after the MFMAs of the
+    // previous step.
+    f32x4 ra[RA], rb[RB];
+    f32x4 s4 = f32x4{1.f, 1.f, 1.f, 1.f}, t4 = f32x4{0.f, 0.f, 0.f, 0.f};
+    unsigned okbits = 0;
+    int kh = 0, kw = 0, coff = 0;   // tap and channel offset of the next K-step to load
+    const int nk = a.K / BK;
 
-    auto gload = [&]() {
-        int th, tw, tc;
-        if (C4) { th = kt_load; tw = c4; tc = 0; }
-        else    { th = kh; tw = kw; tc = coff + c4 * 4; }
-        float4 s4 = make_float4(1.f, 1.f, 1.f, 1.f), t4 = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (a.pre_scale) {
-            s4 = *reinterpret_cast<const float4*>(a.pre_scale + tc);
-            t4 = *reinterpret_cast<const float4*>(a.pre_shift + tc);
-        }
-#pragma unroll
-        for (int i = 0; i < RA; ++i) {
-            const int hi = hi0[i] + th, wi = wi0[i] + tw;
-            const bool ok = mval[i] && (unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (ok) {
-                v = *reinterpret_cast<const float4*>(a.x + abase[i] + ((size_t)hi * a.W + wi) * a.Cin + tc);
-                if (a.pre_scale) {
-                    v.x = fmaxf(v.x * s4.x + t4.x, 0.f);
-                    v.y = fmaxf(v.y * s4.y + t4.y, 0.f);
-                    v.z = fmaxf(v.z * s4.z + t4.z, 0.f);
-                    v.w = fmaxf(v.w * s4.w + t4.w, 0.f);
-                }
-            }
-            ra[i] = v;
-        }
-#pragma unroll
-        for (int i = 0; i < RB; ++i) rb[i] = *reinterpret_cast<const float4*>(wrow[i] + (size_t)kt_load * BK);
-        // advance to the next K-step
-        ++kt_load;
-        if (!C4) {
-            coff += BK;
-            if (coff >= a.Cin) {
-                coff = 0;
-                if (++kw == a.KW) { kw = 0; ++kh; }
-            }
-        }
-    };
-    auto lstore = [&](int buf) {
-#pragma unroll
-        for (int i = 0; i < RA; ++i) *reinterpret_cast<float4*>(&As[buf][(r0 + 32 * i) * LDK + c4 * 4]) = ra[i];
-#pragma unroll
-        for (int i = 0; i < RB; ++i) *reinterpret_cast<float4*>(&Bs[buf][(r0 + 32 * i) * LDK + c4 * 4]) = rb[i];
-    };
+#define FD_GLOAD(KT)                                                                              \
+    do {                                                                                          \
+        const int th_ = C4 ? (KT) : kh;                                                           \
+        const int tw_ = C4 ? c4 : kw;                                                             \
+        const int toff_ = C4 ? (KT) * a.W * 4 : (kh * a.W + kw) * a.Cin + coff;                   \
+        if (a.pre_scale) {                                                                        \
+            s4 = *reinterpret_cast<const f32x4*>(a.pre_scale + coff + c4 * 4);                   \
+            t4 = *reinterpret_cast<const f32x4*>(a.pre_shift + coff + c4 * 4);                   \
+        }                                                                                         \
+        okbits = 0;                                                                               \
+        _Pragma("unroll") for (int i = 0; i < RA; ++i) {                                          \
+            const int hi_ = hi0[i] + th_, wi_ = wi0[i] + tw_;                                     \
+            const bool ok_ = mval[i] && (unsigned)hi_ < (unsigned)a.H && (unsigned)wi_ < (unsigned)a.W; \
+            okbits |= ok_ ? (1u << i) : 0u;                                                       \
+            const float* p_ = ok_ ? xrow[i] + (rowoff[i] + toff_) : a.x;                          \
+            ra[i] = *reinterpret_cast<const f32x4*>(p_);                                         \
+        }                                                                                         \
+        _Pragma("unroll") for (int i = 0; i < RB; ++i)                                            \
+            rb[i] = *reinterpret_cast<const f32x4*>(wrow[i] + (size_t)(KT) * BK);                \
+        if (!C4) {                                                                                \
+            coff += BK;                                                                           \
+            if (coff >= a.Cin) {                                                                  \
+                coff = 0;                                                                         \
+                if (++kw == a.KW) { kw = 0; ++kh; }                                               \
+            }                                                                                     \
+        }                                                                                         \
+    } while (0)
+
+#define FD_LSTORE(BUF)                                                                            \
+    do {                                                                                          \
+        _Pragma("unroll") for (int i = 0; i < RA; ++i) {                                          \
+            f32x4 v_ = ra[i];                                                                    \
+            if (a.pre_scale) {                                                                    \
+                v_.x = fmaxf(v_.x * s4.x + t4.x, 0.f);                                            \
+                v_.y = fmaxf(v_.y * s4.y + t4.y, 0.f);                                            \
+                v_.z = fmaxf(v_.z * s4.z + t4.z, 0.f);                                            \
+                v_.w = fmaxf(v_.w * s4.w + t4.w, 0.f);                                            \
+            }                                                                                     \
+            if (!((okbits >> i) & 1u)) v_ = f32x4{0.f, 0.f, 0.f, 0.f};                      \
+            *reinterpret_cast<f32x4*>(&As[BUF][(r0 + 32 * i) * LDK + c4 * 4]) = v_;              \
+        }                                                                                         \
+        _Pragma("unroll") for (int i = 0; i < RB; ++i)                                            \
+            *reinterpret_cast<f32x4*>(&Bs[BUF][(r0 + 32 * i) * LDK + c4 * 4]) = rb[i];           \
+    } while (0)
 
     f32x16 acc[MT][NT];
 #pragma unroll
@@ -137,16 +150,30 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvKArgs a) {
             for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
 
     const int frow = lane & 31, fcol = (lane >> 5) * 4;
-    auto compute = [&](int buf) {
-        const float* Ab = &As[buf][(wm * (BM / 2) + frow) * LDK + fcol];
-        const float* Bb = &Bs[buf][(wn * (BN / 2) + frow) * LDK + fcol];
+    const int a_frag = (wm * (BM / 2) + frow) * LDK + fcol;
+    const int b_frag = (wn * (BN / 2) + frow) * LDK + fcol;
+
+    FD_GLOAD(0);
+    FD_LSTORE(0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        // The last iteration reloads the final K-step (no branch in the loop body); what it
+        // stages afterwards is never read.
+        const int ktn = (kt + 1 < nk) ? kt + 1 : nk - 1;
+        FD_GLOAD(ktn);
+        // keep the loads above and the LDS staging below the MFMA block: the scheduler would
+        // otherwise sink the loads next to their first use and expose their latency
+        __builtin_amdgcn_sched_barrier(0);
+        const float* Ab = &As[cur][a_frag];
+        const float* Bb = &Bs[cur][b_frag];
 #pragma unroll
         for (int kg = 0; kg < BK / 8; ++kg) {
-            float4 af[MT], bf[NT];
+            f32x4 af[MT], bf[NT];
 #pragma unroll
-            for (int mi = 0; mi < MT; ++mi) af[mi] = *reinterpret_cast<const float4*>(Ab + mi * 32 * LDK + kg * 8);
+            for (int mi = 0; mi < MT; ++mi) af[mi] = *reinterpret_cast<const f32x4*>(Ab + mi * 32 * LDK + kg * 8);
 #pragma unroll
-            for (int ni = 0; ni < NT; ++ni) bf[ni] = *reinterpret_cast<const float4*>(Bb + ni * 32 * LDK + kg * 8);
+            for (int ni = 0; ni < NT; ++ni) bf[ni] = *reinterpret_cast<const f32x4*>(Bb + ni * 32 * LDK + kg * 8);
 #pragma unroll
             for (int mi = 0; mi < MT; ++mi)
 #pragma unroll
@@ -157,41 +184,64 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvKArgs a) {
                     acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mi].w, bf[ni].w, acc[mi][ni], 0, 0, 0);
                 }
         }
-    };
-
-    const int nk = a.K / BK;
-    gload();
-    lstore(0);
-    __syncthreads();
-    for (int kt = 0; kt < nk; ++kt) {
-        const int cur = kt & 1;
-        const bool more = kt + 1 < nk;
-        if (more) gload();
-        compute(cur);
-        if (more) lstore(cur ^ 1);
+        __builtin_amdgcn_sched_barrier(0);
+        FD_LSTORE(cur ^ 1);
         __syncthreads();
     }
+#undef FD_GLOAD
+#undef FD_LSTORE
 
-    // epilogue: C/D layout of the 32x32 tile is col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
+    // Epilogue.  The C/D layout of a 32x32 tile is col = lane & 31, row = (r & 3) + 8 (r >> 2)
+    // + 4 (lane >> 5): storing it directly would issue one 4-byte store per element.  Instead
+    // each wave transposes its rows through its own slice of the (now idle) A staging buffer, 32
+    // rows at a time, and leaves with 16-byte stores; the residual is fetched with matching
+    // 16-byte loads issued before the transpose so their latency is covered.
+    constexpr int WN = BN / 2;                 // wave tile width (32 or 64 floats)
+    constexpr int LDC = WN + 4;                // padded row: 16-byte aligned, conflict-free
+    constexpr int L4 = WN / 4;                 // lanes per row when reading f32x4
+    constexpr int RPP = 64 / L4;               // rows per pass
+    constexpr int PASSES = 32 / RPP;
+    static_assert(2 * BM * LDK >= 4 * 32 * LDC, "A staging buffer too small for the epilogue");
+    float* Cs = &As[0][0] + wave * (32 * LDC);
+    const int erow = lane / L4, ecol = (lane % L4) * 4;
+    const int gcol = tile_n * BN + wn * WN + ecol;
+    const bool col_ok = gcol < a.Cout;         // Cout is a multiple of 4
+    float bias_v[NT];
 #pragma unroll
     for (int ni = 0; ni < NT; ++ni) {
-        const int col = tile_n * BN + wn * (BN / 2) + ni * 32 + (lane & 31);
-        if (col >= a.Cout) continue;
-        const float b = a.bias ? a.bias[col] : 0.f;
+        const int col = tile_n * BN + wn * WN + ni * 32 + (lane & 31);
+        bias_v[ni] = (a.bias && col < a.Cout) ? a.bias[col] : 0.f;
+    }
 #pragma unroll
-        for (int mi = 0; mi < MT; ++mi) {
-            const int rbase = tile_m * BM + wm * (BM / 2) + mi * 32 + 4 * (lane >> 5);
+    for (int mi = 0; mi < MT; ++mi) {
+        const int grow0 = tile_m * BM + wm * (BM / 2) + mi * 32;
+        f32x4 resv[PASSES];
+        if (a.res) {
+#pragma unroll
+            for (int ps = 0; ps < PASSES; ++ps) {
+                const int row = grow0 + ps * RPP + erow;
+                resv[ps] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (row < a.M && col_ok)
+                    resv[ps] = *reinterpret_cast<const f32x4*>(a.res + (size_t)row * a.Cout + gcol);
+            }
+        }
+        __syncthreads();                       // previous use of the staging slice is finished
+#pragma unroll
+        for (int ni = 0; ni < NT; ++ni)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int row = rbase + (r & 3) + 8 * (r >> 2);
-                if (row < a.M) {
-                    float v = acc[mi][ni][r] + b;
-                    if (a.relu) v = fmaxf(v, 0.f);
-                    const size_t o = (size_t)row * a.Cout + col;
-                    if (a.res) v += a.res[o];
-                    a.y[o] = v;
-                }
+                float v = acc[mi][ni][r] + bias_v[ni];
+                if (a.relu) v = fmaxf(v, 0.f);
+                Cs[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * LDC + ni * 32 + (lane & 31)] = v;
             }
+        __syncthreads();
+#pragma unroll
+        for (int ps = 0; ps < PASSES; ++ps) {
+            const int lrow = ps * RPP + erow;
+            const int row = grow0 + lrow;
+            f32x4 v = *reinterpret_cast<const f32x4*>(&Cs[lrow * LDC + ecol]);
+            if (a.res) { v.x += resv[ps].x; v.y += resv[ps].y; v.z += resv[ps].z; v.w += resv[ps].w; }
+            if (row < a.M && col_ok) *reinterpret_cast<f32x4*>(a.y + (size_t)row * a.Cout + gcol) = v;
         }
     }
 }

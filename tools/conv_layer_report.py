@@ -1,0 +1,69 @@
+#!/usr/bin/env python3
+"""Per-layer convolution timing from a rocprofv3 kernel trace of bench.py.
+
+    python tools/conv_layer_report.py <kernel_trace.csv> [micro_batch]
+
+Takes the conv_igemm launches of the last complete forward pass in the trace, pairs them with
+the layer list of faster_rcnn50 at 1080p (same order as the library issues them) and prints
+duration and achieved TFLOP/s per layer."""
+import csv
+import sys
+
+
+def layer_list(B, H=1080, W=1920, R=10):
+    layers = []
+
+    def conv(name, n, h, w, cin, cout, k, s, p):
+        ho, wo = (h + 2 * p - k) // s + 1, (w + 2 * p - k) // s + 1
+        layers.append((name, n * ho * wo, cout, cin * k * k, 2.0 * n * ho * wo * cout * cin * k * k))
+        return ho, wo
+
+    h, w = conv("conv0", B, H, W, 3, 64, 7, 2, 3)
+    h, w = (h + 2 - 3) // 2 + 1, (w + 2 - 3) // 2 + 1
+    F, U = [64, 256, 512, 1024, 2048], [3, 4, 6, 3]
+    cin = 64
+    for s in range(4):
+        if s == 3:
+            conv("rpn3x3", B, h, w, 1024, 512, 3, 1, 1)
+            conv("rpnout", B, h, w, 512, 72, 1, 1, 0)
+            n, h, w = B * R, 7, 7
+        else:
+            n = B
+        cout, mid = F[s + 1], F[s + 1] // 4
+        for u in range(U[s]):
+            st = 2 if (u == 0 and s > 0) else 1
+            nm = "s%du%d" % (s + 1, u + 1)
+            if u == 0:
+                conv(nm + "_sc", n, h, w, cin, cout, 1, st, 0)
+            conv(nm + "_c1", n, h, w, cin, mid, 1, 1, 0)
+            h2, w2 = conv(nm + "_c2", n, h, w, mid, mid, 3, st, 1)
+            conv(nm + "_c3", n, h2, w2, mid, cout, 1, 1, 0)
+            h, w, cin = h2, w2, cout
+    return layers
+
+
+def main():
+    path = sys.argv[1]
+    B = int(sys.argv[2]) if len(sys.argv) > 2 else 8
+    rows = [r for r in csv.DictReader(open(path)) if "conv_igemm" in r["Kernel_Name"]]
+    layers = layer_list(B)
+    last = rows[-len(layers):]
+    tot = totf = 0.0
+    groups = {}
+    for L, r in zip(layers, last):
+        us = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
+        tot += us
+        totf += L[4]
+        kind = L[0].split("_")[-1] if "_" in L[0] else L[0]
+        g = groups.setdefault(kind, [0.0, 0.0])
+        g[0] += us
+        g[1] += L[4]
+        tile = r["Kernel_Name"].split("<")[1].split(">")[0]
+        print("%-9s M=%8d N=%5d K=%5d %9.1f us %7.1f TF  tile %s" % (L[0], L[1], L[2], L[3], us, L[4] / us / 1e6, tile))
+    print("total %.1f us for %d frames = %.2f ms/frame, %.1f TF" % (tot, B, tot / B / 1e3, totf / tot / 1e6))
+    for k, (us, f) in sorted(groups.items(), key=lambda kv: -kv[1][0]):
+        print("  %-8s %9.1f us  %5.1f%%  %6.1f TF" % (k, us, 100 * us / tot, f / us / 1e6))
+
+
+if __name__ == "__main__":
+    main()
