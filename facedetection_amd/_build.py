@@ -20,7 +20,7 @@ SOURCES = [
     ("fd_boxes.hip", ["-ffp-contract=off"]),
     ("fd_image.hip", ["-ffp-contract=off"]),
     ("fd_conv.hip", []),
-    ("fd_net.hip", []),
+    ("fd_conv_split.hip", []),
     ("fd_detector.hip", []),
 ]
 COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]

@@ -72,8 +72,11 @@ SIGNATURES = {
                                C.c_int, vp]),
     "fd_conv2d": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                             vp, vp, vp, C.c_int, vp, vp, vp]),
+    "fd_conv2d_f16x3": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_int,
+                                  C.c_int, vp, vp, vp, C.c_int, vp, vp, vp]),
     "fd_detector_create": (C.c_int, [vp, C.POINTER(Param), C.c_int, C.POINTER(ProposalCfg), C.POINTER(vp)]),
     "fd_detector_destroy": (None, [vp]),
+    "fd_detector_set_precision": (C.c_int, [vp, C.c_int]),
     "fd_detector_set_proposal": (C.c_int, [vp, C.POINTER(ProposalCfg)]),
     "fd_forward": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_float, vp, vp, vp, vp]),
     "fd_detect": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_int, vp, vp, vp, vp]),

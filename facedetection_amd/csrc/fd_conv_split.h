@@ -1,0 +1,39 @@
+// Split-precision (two-way fp16) convolution path; see fd_split.h for the number format.
+#pragma once
+#include "fd_conv.h"
+
+namespace fd {
+
+struct SplitConvParams {
+    ConvShape s;
+    const void* w = nullptr;       // packed split weights [cout_pad][K/32][32 hi | 32 lo], scaled by 1/w_inv_scale
+    float w_inv_scale = 1.f;       // power of two; the accumulator is multiplied by it
+    const float* bias = nullptr;   // [cout] or NULL
+    int relu = 0;
+};
+
+struct SplitConvOut {
+    float* y32 = nullptr;              // float32 output [M][cout] (after bias/relu/residual) or NULL
+    void* ysplit = nullptr;            // split output or NULL
+    const float* post_scale = nullptr; // split output = split(relu(y * post_scale + post_shift)); NULL: split(y)
+    const float* post_shift = nullptr;
+};
+
+int pack_conv_weights_split(const float* w_oihw, int cin_w, const ConvShape& s, const float* out_scale, float wscale,
+                            void* packed, hipStream_t stream);
+
+// x_split: split activations [B][H][W][cin] (or the split staged image for the 7x7 stem).
+int split_conv_forward(const SplitConvParams& p, const void* x_split, int batch, int h, int w, const float* residual,
+                       const SplitConvOut& out, hipStream_t stream);
+
+// float32 [rows][channels] -> split, optionally through relu(x * scale[c] + shift[c]).
+int to_split(const float* x, long long rows, int channels, const float* scale, const float* shift, void* y,
+             hipStream_t stream);
+
+int stage_input_split(const uint8_t* frames, int batch, int h, int w, const InputNorm& norm, void* y,
+                      hipStream_t stream);
+
+int maxpool_3x3s2_split(const float* x, int batch, int h, int w, int c, const float* scale, const float* shift,
+                        float* y32, void* ysplit, hipStream_t stream);
+
+}  // namespace fd

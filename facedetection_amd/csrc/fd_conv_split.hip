@@ -1,0 +1,521 @@
+// Split-precision convolution: the implicit GEMM of fd_conv.hip with both operands carried as
+// two-way fp16 splits (fd_split.h) and the products formed on the f16 matrix cores
+// (v_mfma_f32_32x32x16_f16, three per 32x32x16 block: hi*hi + hi*lo + lo*hi, fp32 accumulate).
+//
+// Because activations arrive already split (the producing kernel's epilogue wrote them that
+// way, with the consumer's BatchNorm+ReLU applied), the input gather is a pure 16-byte copy
+// global -> registers -> LDS for both operands: one 128-byte group [32 hi | 32 lo] of a pixel
+// is one staged row of a K-step.  The epilogue rescales by the weights' power-of-two factor,
+// adds bias / residual, and writes float32 and/or the split form for the next layer.
+#include "fd_conv_split.h"
+#include "fd_split.h"
+
+#include <cfloat>
+#include <cmath>
+#include <string>
+#include <vector>
+
+namespace fd {
+
+struct SplitKArgs {
+    const uint8_t* x;        // split activations (or the split staged image for the stem)
+    const uint8_t* w;        // split packed weights
+    const float* bias;
+    const float* res;        // float32 residual [M][Cout] or NULL
+    float* y32;              // float32 output or NULL
+    uint8_t* ysplit;         // split output or NULL
+    const float* post_scale; // BatchNorm+ReLU applied to the split output only (NULL: raw)
+    const float* post_shift;
+    float w_inv_scale;
+    int H, W, Cin, Ho, Wo, Cout, KW, stride, pad, K, M, relu, tiles_n;
+};
+
+constexpr int SBK = 32;      // k per K-step
+constexpr int SLDK = 36;     // staged row: 128 B of data + 16 B pad, in dwords
+
+template <int BM, int BN, bool STEM>
+__global__ __launch_bounds__(256, 2) void conv_split_kernel(SplitKArgs a) {
+    constexpr int RA = BM / 32, RB = BN / 32;
+    constexpr int MT = BM / 64, NT = BN / 64;
+    __shared__ __attribute__((aligned(16))) float As[2][BM * SLDK];
+    __shared__ __attribute__((aligned(16))) float Bs[2][BN * SLDK];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    int wgid;
+    {
+        const int nwg = gridDim.x, bid = blockIdx.x;
+        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+        wgid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    }
+    const int tile_n = wgid % a.tiles_n, tile_m = wgid / a.tiles_n;
+
+    const int c4 = tid & 7, r0 = tid >> 3;
+    // all offsets in 4-byte units: a split element occupies 4 bytes like a float
+    int hi0[RA], wi0[RA], rowoff[RA];
+    const f32x4* xrow[RA];
+    bool mval[RA];
+    const float* xf = reinterpret_cast<const float*>(a.x);
+#pragma unroll
+    for (int i = 0; i < RA; ++i) {
+        const int m = tile_m * BM + r0 + 32 * i;
+        mval[i] = m < a.M;
+        const int mm = mval[i] ? m : 0;
+        const int hw = a.Ho * a.Wo;
+        const int img = mm / hw;
+        const int rem = mm - img * hw;
+        const int ho = rem / a.Wo;
+        const int wo = rem - ho * a.Wo;
+        hi0[i] = ho * a.stride - a.pad;
+        wi0[i] = wo * a.stride - a.pad;
+        rowoff[i] = (hi0[i] * a.W + wi0[i]) * a.Cin + c4 * 4;
+        xrow[i] = reinterpret_cast<const f32x4*>(xf + (size_t)img * a.H * a.W * a.Cin);
+    }
+    const float* wf = reinterpret_cast<const float*>(a.w);
+    const float* wrow[RB];
+#pragma unroll
+    for (int i = 0; i < RB; ++i) wrow[i] = wf + (size_t)(tile_n * BN + r0 + 32 * i) * a.K + c4 * 4;
+
+    f32x4 ra[RA], rb[RB];
+    unsigned okbits = 0;
+    int kh = 0, kw = 0, coff = 0;
+    const int nk = a.K / SBK;
+
+#define FD_GLOAD(KT)                                                                              \
+    do {                                                                                          \
+        const int th_ = STEM ? (KT) : kh;                                                         \
+        const int tw_ = STEM ? c4 : kw;                                                           \
+        const int toff_ = STEM ? (KT) * a.W * 4 : (kh * a.W + kw) * a.Cin + coff;                 \
+        okbits = 0;                                                                               \
+        _Pragma("unroll") for (int i = 0; i < RA; ++i) {                                          \
+            const int hi_ = hi0[i] + th_, wi_ = wi0[i] + tw_;                                     \
+            const bool ok_ = mval[i] && (unsigned)hi_ < (unsigned)a.H && (unsigned)wi_ < (unsigned)a.W; \
+            okbits |= ok_ ? (1u << i) : 0u;                                                       \
+            const float* p_ = ok_ ? reinterpret_cast<const float*>(xrow[i]) + (rowoff[i] + toff_) : xf; \
+            ra[i] = *reinterpret_cast<const f32x4*>(p_);                                          \
+        }                                                                                         \
+        _Pragma("unroll") for (int i = 0; i < RB; ++i)                                            \
+            rb[i] = *reinterpret_cast<const f32x4*>(wrow[i] + (size_t)(KT) * SBK);                \
+        if (!STEM) {                                                                              \
+            coff += SBK;                                                                          \
+            if (coff >= a.Cin) {                                                                  \
+                coff = 0;                                                                         \
+                if (++kw == a.KW) { kw = 0; ++kh; }                                               \
+            }                                                                                     \
+        }                                                                                         \
+    } while (0)
+
+    // Stem: a thread's 16 bytes are one pixel [4 hi | 4 lo]; its halves go to the hi and lo
+    // sections of the staged row (k = 4 kw + c).  Otherwise the 16-byte chunk is copied as is.
+#define FD_LSTORE(BUF)                                                                            \
+    do {                                                                                          \
+        _Pragma("unroll") for (int i = 0; i < RA; ++i) {                                          \
+            f32x4 v_ = ra[i];                                                                     \
+            if (!((okbits >> i) & 1u)) v_ = f32x4{0.f, 0.f, 0.f, 0.f};                            \
+            float* row_ = &As[BUF][(r0 + 32 * i) * SLDK];                                         \
+            if (STEM) {                                                                           \
+                *reinterpret_cast<float2*>(row_ + c4 * 2) = make_float2(v_[0], v_[1]);            \
+                *reinterpret_cast<float2*>(row_ + 16 + c4 * 2) = make_float2(v_[2], v_[3]);       \
+            } else {                                                                              \
+                *reinterpret_cast<f32x4*>(row_ + c4 * 4) = v_;                                    \
+            }                                                                                     \
+        }                                                                                         \
+        _Pragma("unroll") for (int i = 0; i < RB; ++i)                                            \
+            *reinterpret_cast<f32x4*>(&Bs[BUF][(r0 + 32 * i) * SLDK + c4 * 4]) = rb[i];           \
+    } while (0)
+
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NT; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+
+    // fragment of k-group kg (16 k): lane (row = lane & 31, half = lane >> 5) reads halves
+    // 16 kg + 8 half .. + 7 of the hi section (dwords 0..15) and of the lo section (dwords 16..31)
+    const int frow = lane & 31, fcol = (lane >> 5) * 4;
+    const int a_frag = (wm * (BM / 2) + frow) * SLDK + fcol;
+    const int b_frag = (wn * (BN / 2) + frow) * SLDK + fcol;
+
+    FD_GLOAD(0);
+    FD_LSTORE(0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        const int ktn = (kt + 1 < nk) ? kt + 1 : nk - 1;
+        FD_GLOAD(ktn);
+        __builtin_amdgcn_sched_barrier(0);
+        const float* Ab = &As[cur][a_frag];
+        const float* Bb = &Bs[cur][b_frag];
+#pragma unroll
+        for (int kg = 0; kg < 2; ++kg) {
+            f16x8 ah[MT], al[MT], bh[NT], bl[NT];
+#pragma unroll
+            for (int mi = 0; mi < MT; ++mi) {
+                ah[mi] = *reinterpret_cast<const f16x8*>(Ab + mi * 32 * SLDK + kg * 8);
+                al[mi] = *reinterpret_cast<const f16x8*>(Ab + mi * 32 * SLDK + 16 + kg * 8);
+            }
+#pragma unroll
+            for (int ni = 0; ni < NT; ++ni) {
+                bh[ni] = *reinterpret_cast<const f16x8*>(Bb + ni * 32 * SLDK + kg * 8);
+                bl[ni] = *reinterpret_cast<const f16x8*>(Bb + ni * 32 * SLDK + 16 + kg * 8);
+            }
+#pragma unroll
+            for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < NT; ++ni) {
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[mi], bh[ni], acc[mi][ni], 0, 0, 0);
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mi], bl[ni], acc[mi][ni], 0, 0, 0);
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mi], bh[ni], acc[mi][ni], 0, 0, 0);
+                }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        FD_LSTORE(cur ^ 1);
+        __syncthreads();
+    }
+#undef FD_GLOAD
+#undef FD_LSTORE
+
+    // Epilogue: transpose each wave's rows through its slice of the A staging buffer (32 rows at
+    // a time); every lane then owns 8 consecutive channels of a row: two 16-byte float32 stores
+    // and/or one 16-byte hi store plus one 16-byte lo store of the split form.
+    constexpr int WN = BN / 2;
+    constexpr int LDC = WN + 4;
+    constexpr int L8 = WN / 8;                 // lanes per row
+    constexpr int RPP = 64 / L8;               // rows per pass
+    constexpr int PASSES = 32 / RPP;
+    static_assert(2 * BM * SLDK >= 4 * 32 * LDC, "A staging buffer too small for the epilogue");
+    float* Cs = &As[0][0] + wave * (32 * LDC);
+    const int erow = lane / L8, ecol = (lane % L8) * 8;
+    const int gcol = tile_n * BN + wn * WN + ecol;
+    const bool col_ok = gcol < a.Cout;         // Cout is a multiple of 8
+    float bias_v[NT];
+#pragma unroll
+    for (int ni = 0; ni < NT; ++ni) {
+        const int col = tile_n * BN + wn * WN + ni * 32 + (lane & 31);
+        bias_v[ni] = (a.bias && col < a.Cout) ? a.bias[col] : 0.f;
+    }
+    f32x4 ps0 = {1.f, 1.f, 1.f, 1.f}, ps1 = ps0, pt0 = {0.f, 0.f, 0.f, 0.f}, pt1 = pt0;
+    const bool post = a.ysplit && a.post_scale && col_ok;
+    if (post) {
+        ps0 = *reinterpret_cast<const f32x4*>(a.post_scale + gcol);
+        ps1 = *reinterpret_cast<const f32x4*>(a.post_scale + gcol + 4);
+        pt0 = *reinterpret_cast<const f32x4*>(a.post_shift + gcol);
+        pt1 = *reinterpret_cast<const f32x4*>(a.post_shift + gcol + 4);
+    }
+#pragma unroll
+    for (int mi = 0; mi < MT; ++mi) {
+        const int grow0 = tile_m * BM + wm * (BM / 2) + mi * 32;
+        f32x4 res0[PASSES], res1[PASSES];
+        if (a.res) {
+#pragma unroll
+            for (int ps = 0; ps < PASSES; ++ps) {
+                const int row = grow0 + ps * RPP + erow;
+                res0[ps] = f32x4{0.f, 0.f, 0.f, 0.f};
+                res1[ps] = res0[ps];
+                if (row < a.M && col_ok) {
+                    const float* rp = a.res + (size_t)row * a.Cout + gcol;
+                    res0[ps] = *reinterpret_cast<const f32x4*>(rp);
+                    res1[ps] = *reinterpret_cast<const f32x4*>(rp + 4);
+                }
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int ni = 0; ni < NT; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float v = acc[mi][ni][r] * a.w_inv_scale + bias_v[ni];
+                if (a.relu) v = fmaxf(v, 0.f);
+                Cs[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * LDC + ni * 32 + (lane & 31)] = v;
+            }
+        __syncthreads();
+#pragma unroll
+        for (int ps = 0; ps < PASSES; ++ps) {
+            const int lrow = ps * RPP + erow;
+            const int row = grow0 + lrow;
+            f32x4 v0 = *reinterpret_cast<const f32x4*>(&Cs[lrow * LDC + ecol]);
+            f32x4 v1 = *reinterpret_cast<const f32x4*>(&Cs[lrow * LDC + ecol + 4]);
+            if (a.res) { v0 += res0[ps]; v1 += res1[ps]; }
+            if (row < a.M && col_ok) {
+                if (a.y32) {
+                    float* yp = a.y32 + (size_t)row * a.Cout + gcol;
+                    *reinterpret_cast<f32x4*>(yp) = v0;
+                    *reinterpret_cast<f32x4*>(yp + 4) = v1;
+                }
+                if (a.ysplit) {
+                    if (post) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            v0[j] = fmaxf(v0[j] * ps0[j] + pt0[j], 0.f);
+                            v1[j] = fmaxf(v1[j] * ps1[j] + pt1[j], 0.f);
+                        }
+                    }
+                    f16x8 hi, lo;
+                    split8(v0, v1, hi, lo);
+                    uint8_t* sp = a.ysplit + (size_t)row * a.Cout * 4 + split_offset(gcol);
+                    *reinterpret_cast<f16x8*>(sp) = hi;
+                    *reinterpret_cast<f16x8*>(sp + 64) = lo;
+                }
+            }
+        }
+    }
+}
+
+template <int BM, int BN, bool STEM>
+static int launch_split(const SplitKArgs& a, hipStream_t stream) {
+    static const std::string name =
+        std::string("conv_split_") + std::to_string(BM) + "x" + std::to_string(BN) + (STEM ? "_stem" : "");
+    const double taps = STEM ? 147.0 : (double)a.K;
+    const double cin_bytes = STEM ? 16.0 : 4.0 * a.Cin;
+    ProfScope scope(stream, name.c_str(), 2.0 * a.M * a.Cout * taps,
+                    (double)a.H * a.W * (a.M / ((double)a.Ho * a.Wo)) * cin_bytes + 4.0 * a.Cout * taps +
+                        4.0 * a.M * a.Cout * ((a.res ? 1.0 : 0.0) + (a.y32 ? 1.0 : 0.0) + (a.ysplit ? 1.0 : 0.0)));
+    SplitKArgs k = a;
+    const int tiles_m = ceil_div(a.M, BM);
+    k.tiles_n = ceil_div(a.Cout, BN);
+    hipLaunchKernelGGL((conv_split_kernel<BM, BN, STEM>), dim3(tiles_m * k.tiles_n), dim3(256), 0, stream, k);
+    FD_LAUNCH_CHECK();
+    return FD_OK;
+}
+
+int split_conv_forward(const SplitConvParams& p, const void* x_split, int batch, int h, int w, const float* residual,
+                       const SplitConvOut& out, hipStream_t stream) {
+    const ConvShape& s = p.s;
+    FD_REQUIRE(x_split && p.w && (out.y32 || out.ysplit), "split conv: NULL tensor");
+    FD_REQUIRE(batch > 0 && h > 0 && w > 0, "split conv: bad input shape %d x %d x %d", batch, h, w);
+    const bool stem = (s.cin == 4);
+    FD_REQUIRE(stem ? (s.kwp == 8) : (s.cin % 32 == 0 && s.kwp == s.kw),
+               "split conv: input channels must be a multiple of 32 (or the staged image), got %d", s.cin);
+    FD_REQUIRE(s.cout % 8 == 0, "split conv: output channels must be a multiple of 8, got %d", s.cout);
+    FD_REQUIRE(!out.ysplit || s.cout % 32 == 0, "split conv: a split output needs a multiple of 32 channels");
+    const int ho = s.out_h(h), wo = s.out_w(w);
+    FD_REQUIRE(ho > 0 && wo > 0, "split conv: empty output");
+    const long long m_ll = (long long)batch * ho * wo;
+    FD_REQUIRE(m_ll < (1ll << 31) / 4, "split conv: too many output pixels (%lld)", m_ll);
+    SplitKArgs a;
+    a.x = static_cast<const uint8_t*>(x_split);
+    a.w = static_cast<const uint8_t*>(p.w);
+    a.bias = p.bias; a.res = residual; a.y32 = out.y32; a.ysplit = static_cast<uint8_t*>(out.ysplit);
+    a.post_scale = out.post_scale; a.post_shift = out.post_shift; a.w_inv_scale = p.w_inv_scale;
+    a.H = h; a.W = w; a.Cin = s.cin; a.Ho = ho; a.Wo = wo; a.Cout = s.cout; a.KW = s.kwp;
+    a.stride = s.stride; a.pad = s.pad; a.K = s.k(); a.M = (int)m_ll; a.relu = p.relu; a.tiles_n = 0;
+    if (stem) return launch_split<128, 64, true>(a, stream);
+    const long long t128 = (long long)ceil_div(a.M, 128) * ceil_div(s.cout, 128);
+    const long long t12864 = (long long)ceil_div(a.M, 128) * ceil_div(s.cout, 64);
+    if (s.cout > 64 && t128 >= 384) return launch_split<128, 128, false>(a, stream);
+    if (t12864 >= 384) return launch_split<128, 64, false>(a, stream);
+    return launch_split<64, 64, false>(a, stream);
+}
+
+// ---------------------------------------------------------------------------------
+// Weight packing: OIHW float32 -> [cout_pad][K/32][32 hi | 32 lo] of w * out_scale[o] * wscale
+__global__ __launch_bounds__(256) void pack_split_kernel(const float* __restrict__ w, int cout, int cin_w, int kh, int kw,
+                                                        int kwp, int cin_p, int cout_pad,
+                                                        const float* __restrict__ scale, float wscale,
+                                                        uint8_t* __restrict__ out) {
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long K = (long long)kh * kwp * cin_p;
+    if (t >= (long long)cout_pad * K) return;
+    const int k = (int)(t % K);
+    const int o = (int)(t / K);
+    const int c = k % cin_p;
+    const int x = (k / cin_p) % kwp;
+    const int y = k / (cin_p * kwp);
+    float v = 0.f;
+    if (o < cout && x < kw && c < cin_w) {
+        v = w[(((size_t)o * cin_w + c) * kh + y) * kw + x];
+        if (scale) v *= scale[o];
+        v *= wscale;
+    }
+    _Float16 hi, lo;
+    split_f32(v, hi, lo);
+    uint8_t* row = out + (size_t)o * K * 4 + (size_t)(k >> 5) * 128 + (size_t)(k & 31) * 2;
+    *reinterpret_cast<_Float16*>(row) = hi;
+    *reinterpret_cast<_Float16*>(row + 64) = lo;
+}
+
+int pack_conv_weights_split(const float* w_oihw, int cin_w, const ConvShape& s, const float* out_scale, float wscale,
+                            void* packed, hipStream_t stream) {
+    FD_REQUIRE(w_oihw && packed && cin_w > 0 && cin_w <= s.cin && s.k() % 32 == 0, "pack_conv_weights_split: bad arguments");
+    const long long total = (long long)s.cout_pad() * s.k();
+    hipLaunchKernelGGL(pack_split_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, stream, w_oihw, s.cout, cin_w, s.kh,
+                       s.kw, s.kwp, s.cin, s.cout_pad(), out_scale, wscale, static_cast<uint8_t*>(packed));
+    FD_LAUNCH_CHECK();
+    return FD_OK;
+}
+
+// ---------------------------------------------------------------------------------
+// float32 [rows][C] -> split [rows][C], optionally through relu(x * scale[c] + shift[c])
+__global__ __launch_bounds__(256) void to_split_kernel(const float* __restrict__ x, long long rows, int C,
+                                                      const float* __restrict__ scale, const float* __restrict__ shift,
+                                                      uint8_t* __restrict__ y) {
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;     // one thread per 8 channels
+    const int c8n = C / 8;
+    if (t >= rows * c8n) return;
+    const int c = (int)(t % c8n) * 8;
+    const long long r = t / c8n;
+    f32x4 v0 = *reinterpret_cast<const f32x4*>(x + r * C + c);
+    f32x4 v1 = *reinterpret_cast<const f32x4*>(x + r * C + c + 4);
+    if (scale) {
+        const f32x4 s0 = *reinterpret_cast<const f32x4*>(scale + c), s1 = *reinterpret_cast<const f32x4*>(scale + c + 4);
+        const f32x4 t0 = *reinterpret_cast<const f32x4*>(shift + c), t1 = *reinterpret_cast<const f32x4*>(shift + c + 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            v0[j] = fmaxf(v0[j] * s0[j] + t0[j], 0.f);
+            v1[j] = fmaxf(v1[j] * s1[j] + t1[j], 0.f);
+        }
+    }
+    f16x8 hi, lo;
+    split8(v0, v1, hi, lo);
+    uint8_t* sp = y + (size_t)r * C * 4 + split_offset(c);
+    *reinterpret_cast<f16x8*>(sp) = hi;
+    *reinterpret_cast<f16x8*>(sp + 64) = lo;
+}
+
+int to_split(const float* x, long long rows, int channels, const float* scale, const float* shift, void* y,
+             hipStream_t stream) {
+    FD_REQUIRE(x && y && channels % 32 == 0, "to_split: channels must be a multiple of 32");
+    if (rows <= 0) return FD_OK;
+    ProfScope scope(stream, "to_split", 0.0, 8.0 * (double)rows * channels);
+    hipLaunchKernelGGL(to_split_kernel, dim3(ceil_div(rows * (channels / 8), 256)), dim3(256), 0, stream, x, rows,
+                       channels, scale, shift, static_cast<uint8_t*>(y));
+    FD_LAUNCH_CHECK();
+    return FD_OK;
+}
+
+// ---------------------------------------------------------------------------------
+// uint8 frames -> split staged image [B][H][W][4 hi | 4 lo] with bn_data applied
+__global__ __launch_bounds__(256) void stage_input_split_kernel(const uint8_t* __restrict__ f, long long pixels,
+                                                               InputNorm n, f16x8* __restrict__ y) {
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= pixels) return;
+    const uint8_t* p = f + t * 3;
+    f16x8 o;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        _Float16 hi, lo;
+        split_f32((float)p[c] * n.scale[c] + n.shift[c], hi, lo);
+        o[c] = hi;
+        o[4 + c] = lo;
+    }
+    o[3] = (_Float16)0.f;
+    o[7] = (_Float16)0.f;
+    y[t] = o;
+}
+
+int stage_input_split(const uint8_t* frames, int batch, int h, int w, const InputNorm& norm, void* y,
+                      hipStream_t stream) {
+    FD_REQUIRE(frames && y, "stage_input_split: NULL tensor");
+    const long long pixels = (long long)batch * h * w;
+    ProfScope scope(stream, "stage_input", 0.0, 19.0 * (double)pixels);
+    hipLaunchKernelGGL(stage_input_split_kernel, dim3(ceil_div(pixels, 256)), dim3(256), 0, stream, frames, pixels, norm,
+                       static_cast<f16x8*>(y));
+    FD_LAUNCH_CHECK();
+    return FD_OK;
+}
+
+// ---------------------------------------------------------------------------------
+// 3x3/2 max pooling of a float32 map, written as float32 (optional) and as the split of
+// relu(max * scale[c] + shift[c]) for the first residual unit.
+__global__ __launch_bounds__(256) void maxpool_split_kernel(const float* __restrict__ x, int B, int H, int W, int C, int Ho,
+                                                           int Wo, const float* __restrict__ scale,
+                                                           const float* __restrict__ shift, float* __restrict__ y32,
+                                                           uint8_t* __restrict__ ysplit) {
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    const int c8n = C / 8;
+    if (t >= (long long)B * Ho * Wo * c8n) return;
+    const int c = (int)(t % c8n) * 8;
+    const long long pix = t / c8n;
+    const int wo = (int)(pix % Wo);
+    const int ho = (int)((pix / Wo) % Ho);
+    const int b = (int)(pix / ((long long)Wo * Ho));
+    f32x4 m0 = {-FLT_MAX, -FLT_MAX, -FLT_MAX, -FLT_MAX}, m1 = m0;
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy) {
+        const int hi = ho * 2 - 1 + dy;
+        if ((unsigned)hi >= (unsigned)H) continue;
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) {
+            const int wi = wo * 2 - 1 + dx;
+            if ((unsigned)wi >= (unsigned)W) continue;
+            const float* p = x + (((size_t)b * H + hi) * W + wi) * C + c;
+            const f32x4 v0 = *reinterpret_cast<const f32x4*>(p), v1 = *reinterpret_cast<const f32x4*>(p + 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { m0[j] = fmaxf(m0[j], v0[j]); m1[j] = fmaxf(m1[j], v1[j]); }
+        }
+    }
+    if (y32) {
+        *reinterpret_cast<f32x4*>(y32 + pix * C + c) = m0;
+        *reinterpret_cast<f32x4*>(y32 + pix * C + c + 4) = m1;
+    }
+    if (ysplit) {
+        if (scale) {
+            const f32x4 s0 = *reinterpret_cast<const f32x4*>(scale + c), s1 = *reinterpret_cast<const f32x4*>(scale + c + 4);
+            const f32x4 t0 = *reinterpret_cast<const f32x4*>(shift + c), t1 = *reinterpret_cast<const f32x4*>(shift + c + 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                m0[j] = fmaxf(m0[j] * s0[j] + t0[j], 0.f);
+                m1[j] = fmaxf(m1[j] * s1[j] + t1[j], 0.f);
+            }
+        }
+        f16x8 hi, lo;
+        split8(m0, m1, hi, lo);
+        uint8_t* sp = ysplit + (size_t)pix * C * 4 + split_offset(c);
+        *reinterpret_cast<f16x8*>(sp) = hi;
+        *reinterpret_cast<f16x8*>(sp + 64) = lo;
+    }
+}
+
+int maxpool_3x3s2_split(const float* x, int batch, int h, int w, int c, const float* scale, const float* shift,
+                        float* y32, void* ysplit, hipStream_t stream) {
+    FD_REQUIRE(x && (y32 || ysplit) && c % 32 == 0, "maxpool (split): bad arguments");
+    const int ho = (h + 2 - 3) / 2 + 1, wo = (w + 2 - 3) / 2 + 1;
+    const long long total = (long long)batch * ho * wo * (c / 8);
+    ProfScope scope(stream, "maxpool_3x3s2", 0.0,
+                    4.0 * c * ((double)batch * h * w + (double)batch * ho * wo * ((y32 ? 1 : 0) + (ysplit ? 1 : 0))));
+    hipLaunchKernelGGL(maxpool_split_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, stream, x, batch, h, w, c, ho, wo,
+                       scale, shift, y32, static_cast<uint8_t*>(ysplit));
+    FD_LAUNCH_CHECK();
+    return FD_OK;
+}
+
+}  // namespace fd
+
+// =================================================================================
+// C ABI: the convolution operator of fd_conv2d computed with split-precision operands
+// =================================================================================
+extern "C" {
+
+int fd_conv2d_f16x3(fd_ctx* ctx, const float* x_nhwc, int batch, int height, int width, int cin, const float* w_oihw,
+                    int cout, int kh, int kw, int stride, int pad, const float* bias, const float* pre_scale,
+                    const float* pre_shift, int relu, const float* residual, float* y_nhwc, void* stream) {
+    FD_REQUIRE(ctx && x_nhwc && w_oihw && y_nhwc, "fd_conv2d_f16x3: NULL argument");
+    FD_REQUIRE(cin % 32 == 0 && cin > 0 && cout > 0 && cout % 8 == 0,
+               "fd_conv2d_f16x3: cin must be a multiple of 32 and cout of 8 (got %d, %d)", cin, cout);
+    hipStream_t st = fd::as_stream(stream);
+    fd::SplitConvParams p;
+    p.s.cin = cin; p.s.cout = cout; p.s.kh = kh; p.s.kw = kw; p.s.kwp = kw; p.s.stride = stride; p.s.pad = pad;
+    // weight scale from the largest magnitude (blocking read-back: this entry point is for tests)
+    const size_t nw = (size_t)cout * cin * kh * kw;
+    std::vector<float> host(nw);
+    FD_HIP(hipStreamSynchronize(st));
+    FD_HIP(hipMemcpy(host.data(), w_oihw, nw * sizeof(float), hipMemcpyDeviceToHost));
+    double wmax = 0.0;
+    for (float v : host) wmax = std::fmax(wmax, std::fabs((double)v));
+    float wscale = 1.f;
+    if (wmax > 0.0 && std::isfinite(wmax)) wscale = (float)std::ldexp(1.0, 13 - (int)std::floor(std::log2(wmax)));
+    void* packed = nullptr;
+    void* xs = nullptr;
+    FD_TRY(fd::scratch(ctx, fd::SLOT_MISC0, p.s.packed_floats() * sizeof(float), &packed));
+    FD_TRY(fd::scratch(ctx, fd::SLOT_MISC1, (size_t)batch * height * width * cin * sizeof(float), &xs));
+    FD_TRY(fd::pack_conv_weights_split(w_oihw, cin, p.s, nullptr, wscale, packed, st));
+    FD_TRY(fd::to_split(x_nhwc, (long long)batch * height * width, cin, pre_scale, pre_shift, xs, st));
+    p.w = packed; p.w_inv_scale = 1.0f / wscale; p.bias = bias; p.relu = relu;
+    fd::SplitConvOut o;
+    o.y32 = y_nhwc;
+    return fd::split_conv_forward(p, xs, batch, height, width, residual, o, st);
+}
+
+}  // extern "C"

@@ -4,6 +4,7 @@
 // candidate / keep counts stay on the device and every grid is sized from shape bounds.
 #include "fd_boxes.h"
 #include "fd_conv.h"
+#include "fd_conv_split.h"
 
 #include <cmath>
 #include <cstring>
@@ -20,6 +21,8 @@ constexpr int POOLED = 7;
 
 struct Unit {
     ConvParams conv1, conv2, conv3, sc;
+    SplitConvParams s_conv1, s_conv2, s_conv3, s_sc;
+    const float *bn1_scale = nullptr, *bn1_shift = nullptr;   // the unit's input BatchNorm (device)
     bool has_sc = false;
 };
 
@@ -31,7 +34,7 @@ struct Tap {
 
 enum NetBuf {
     NB_STAGED = 0, NB_CONV0, NB_XA, NB_XB, NB_T1, NB_T2, NB_SC, NB_RPN_HID, NB_RPN_OUT, NB_ROIS, NB_ROI_SCORES,
-    NB_POOLED, NB_X4A, NB_X4B, NB_FLAT, NB_CLS, NB_BOX, NB_COUNTS, NB_COUNT
+    NB_POOLED, NB_X4A, NB_X4B, NB_FLAT, NB_CLS, NB_BOX, NB_COUNTS, NB_ACT_A, NB_ACT_B, NB_COUNT
 };
 
 }  // namespace fd
@@ -44,6 +47,8 @@ struct fd_detector {
     fd::ConvParams conv0;
     std::vector<fd::Unit> stage[4];
     fd::ConvParams rpn_conv, rpn_out;
+    fd::SplitConvParams s_conv0, s_rpn_conv, s_rpn_out;
+    int precision = FD_PRECISION_F16X3;
     const float *bn1_scale = nullptr, *bn1_shift = nullptr;
     const float *w_cls = nullptr, *b_cls = nullptr, *w_box = nullptr, *b_box = nullptr;
     int32_t* nan_flag = nullptr;
@@ -102,7 +107,7 @@ static int bn_fold(const ParamTable& t, const std::string& name, int ch, bool fi
 
 // Uploads OIHW weights, packs them for the GEMM (scaled per output channel when out_scale is given).
 static int make_conv(fd_detector* d, const float* w_host, int cin_w, ConvShape s, const std::vector<float>* out_scale,
-                     const std::vector<float>* bias, int relu, ConvParams* out) {
+                     const std::vector<float>* bias, int relu, ConvParams* out, SplitConvParams* sout) {
     float *raw = nullptr, *scale_d = nullptr, *packed = nullptr, *bias_d = nullptr;
     const size_t nraw = (size_t)s.cout * cin_w * s.kh * s.kw;
     FD_HIP(hipMalloc((void**)&raw, nraw * sizeof(float)));
@@ -114,6 +119,25 @@ static int make_conv(fd_detector* d, const float* w_host, int cin_w, ConvShape s
     FD_HIP(hipMalloc((void**)&packed, s.packed_floats() * sizeof(float)));
     d->owned.push_back(packed);
     FD_TRY(pack_conv_weights(raw, cin_w, s, scale_d, packed, nullptr));
+    // split form: weights (with the folded BatchNorm scale) times a power of two that brings the
+    // largest magnitude to [2^13, 2^14), so that their lo halves stay clear of fp16 subnormals
+    void* packed_split = nullptr;
+    float wscale = 1.f;
+    {
+        const size_t per_out = (size_t)cin_w * s.kh * s.kw;
+        double wmax = 0.0;
+        for (int o = 0; o < s.cout; ++o) {
+            const double sc = out_scale ? std::fabs((double)(*out_scale)[o]) : 1.0;
+            for (size_t i = 0; i < per_out; ++i) {
+                const double v = std::fabs((double)w_host[o * per_out + i]) * sc;
+                if (v > wmax) wmax = v;
+            }
+        }
+        if (wmax > 0.0 && std::isfinite(wmax)) wscale = (float)std::ldexp(1.0, 13 - (int)std::floor(std::log2(wmax)));
+        FD_HIP(hipMalloc(&packed_split, s.packed_floats() * sizeof(float)));
+        d->owned.push_back(packed_split);
+        FD_TRY(pack_conv_weights_split(raw, cin_w, s, scale_d, wscale, packed_split, nullptr));
+    }
     FD_HIP(hipDeviceSynchronize());
     FD_HIP(hipFree(raw));
     if (scale_d) FD_HIP(hipFree(scale_d));
@@ -122,6 +146,11 @@ static int make_conv(fd_detector* d, const float* w_host, int cin_w, ConvShape s
     out->w = packed;
     out->bias = bias_d;
     out->relu = relu;
+    sout->s = s;
+    sout->w = packed_split;
+    sout->w_inv_scale = 1.0f / wscale;
+    sout->bias = bias_d;
+    sout->relu = relu;
     return FD_OK;
 }
 
@@ -147,16 +176,18 @@ static int build_unit(fd_detector* d, const ParamTable& t, const std::string& na
     float *pre_s = nullptr, *pre_h = nullptr;
     FD_TRY(upload(d, s1.data(), s1.size(), &pre_s));
     FD_TRY(upload(d, h1.data(), h1.size(), &pre_h));
-    FD_TRY(make_conv(d, w1->data_host, cin, shape(cin, mid, 1, 1, 0), &s2, &h2, 1, &u->conv1));
+    FD_TRY(make_conv(d, w1->data_host, cin, shape(cin, mid, 1, 1, 0), &s2, &h2, 1, &u->conv1, &u->s_conv1));
     u->conv1.pre_scale = pre_s;
     u->conv1.pre_shift = pre_h;
-    FD_TRY(make_conv(d, w2->data_host, mid, shape(mid, mid, 3, stride, 1), &s3, &h3, 1, &u->conv2));
-    FD_TRY(make_conv(d, w3->data_host, mid, shape(mid, cout, 1, 1, 0), nullptr, nullptr, 0, &u->conv3));
+    u->bn1_scale = pre_s;
+    u->bn1_shift = pre_h;
+    FD_TRY(make_conv(d, w2->data_host, mid, shape(mid, mid, 3, stride, 1), &s3, &h3, 1, &u->conv2, &u->s_conv2));
+    FD_TRY(make_conv(d, w3->data_host, mid, shape(mid, cout, 1, 1, 0), nullptr, nullptr, 0, &u->conv3, &u->s_conv3));
     u->has_sc = !dim_match;
     if (u->has_sc) {
         const fd_param* ws = t.get(name + "_sc_weight", (int64_t)cout * cin);
         if (!ws) return FD_ERR_PARAM;
-        FD_TRY(make_conv(d, ws->data_host, cin, shape(cin, cout, 1, stride, 0), nullptr, nullptr, 0, &u->sc));
+        FD_TRY(make_conv(d, ws->data_host, cin, shape(cin, cout, 1, stride, 0), nullptr, nullptr, 0, &u->sc, &u->s_sc));
         u->sc.pre_scale = pre_s;
         u->sc.pre_shift = pre_h;
     }
@@ -174,7 +205,7 @@ static int build(fd_detector* d, const ParamTable& t) {
     if (!w0) return FD_ERR_PARAM;
     ConvShape s0 = shape(4, FILTERS[0], 7, 2, 3);
     s0.kwp = 8;
-    FD_TRY(make_conv(d, w0->data_host, 3, s0, &sc, &sh, 1, &d->conv0));
+    FD_TRY(make_conv(d, w0->data_host, 3, s0, &sc, &sh, 1, &d->conv0, &d->s_conv0));
     int cin = FILTERS[0];
     for (int s = 0; s < 4; ++s) {
         const int cout = FILTERS[s + 1];
@@ -192,7 +223,7 @@ static int build(fd_detector* d, const ParamTable& t) {
         const fd_param* b = t.get("rpn_conv_3x3_bias", 512);
         if (!w || !b) return FD_ERR_PARAM;
         std::vector<float> bias(b->data_host, b->data_host + 512);
-        FD_TRY(make_conv(d, w->data_host, 1024, shape(1024, 512, 3, 1, 1), nullptr, &bias, 1, &d->rpn_conv));
+        FD_TRY(make_conv(d, w->data_host, 1024, shape(1024, 512, 3, 1, 1), nullptr, &bias, 1, &d->rpn_conv, &d->s_rpn_conv));
         const int A = d->prop.num_ratios * d->prop.num_scales;
         const fd_param* wc = t.get("rpn_cls_score_weight", 2ll * A * 512);
         const fd_param* bc = t.get("rpn_cls_score_bias", 2 * A);
@@ -204,7 +235,7 @@ static int build(fd_detector* d, const ParamTable& t) {
         memcpy(wcat.data() + 2ull * A * 512, wb->data_host, sizeof(float) * 4 * A * 512);
         memcpy(bcat.data(), bc->data_host, sizeof(float) * 2 * A);
         memcpy(bcat.data() + 2 * A, bb->data_host, sizeof(float) * 4 * A);
-        FD_TRY(make_conv(d, wcat.data(), 512, shape(512, 6 * A, 1, 1, 0), nullptr, &bcat, 0, &d->rpn_out));
+        FD_TRY(make_conv(d, wcat.data(), 512, shape(512, 6 * A, 1, 1, 0), nullptr, &bcat, 0, &d->rpn_out, &d->s_rpn_out));
     }
     // head: bn1 + relu + global average, then the two FullyConnected layers
     FD_TRY(bn_fold(t, "bn1", FILTERS[4], false, sc, sh));
@@ -382,6 +413,170 @@ static int run_graph(Plan& pl, const uint8_t* frames, int B, int H, int W, float
     return FD_OK;
 }
 
+// ----------------------------------------------------------------------------- split-precision graph
+// Same layer sequence with every convolution on the f16 matrix cores (fd_conv_split.hip).
+// A unit consumes act = split(relu(bn1(x))) -- written by whoever produced x -- and, when its
+// shortcut is the identity, the raw float32 x.
+static int run_unit_split(Plan& pl, const Unit& u, const char* name, const void* act, const float* xraw, int n, int h,
+                          int w, float* y32, void* ysplit, const float* next_scale, const float* next_shift,
+                          int* ho_out, int* wo_out) {
+    const int mid = u.s_conv1.s.cout, cout = u.s_conv3.s.cout;
+    const int ho = u.s_conv2.s.out_h(h), wo = u.s_conv2.s.out_w(w);
+    float* t1 = pl.buf(NB_T1, (size_t)n * h * w * mid);
+    float* t2 = pl.buf(NB_T2, (size_t)n * ho * wo * mid);
+    const float* res = xraw;
+    if (u.has_sc) {
+        float* s = pl.buf(NB_SC, (size_t)n * ho * wo * cout);
+        if (!pl.dry) {
+            SplitConvOut o;
+            o.y32 = s;
+            FD_TRY(split_conv_forward(u.s_sc, act, n, h, w, nullptr, o, pl.stream));
+        }
+        res = s;
+    }
+    if (!pl.dry) {
+        SplitConvOut o1, o2, o3;
+        o1.ysplit = t1;
+        o2.ysplit = t2;
+        o3.y32 = y32;
+        o3.ysplit = ysplit;
+        o3.post_scale = next_scale;
+        o3.post_shift = next_shift;
+        FD_TRY(split_conv_forward(u.s_conv1, act, n, h, w, nullptr, o1, pl.stream));
+        FD_TRY(split_conv_forward(u.s_conv2, t1, n, h, w, nullptr, o2, pl.stream));
+        FD_TRY(split_conv_forward(u.s_conv3, t2, n, ho, wo, res, o3, pl.stream));
+    }
+    if (y32) pl.tap(name, y32, n, ho, wo, cout);
+    *ho_out = ho;
+    *wo_out = wo;
+    return FD_OK;
+}
+
+static int run_graph_split(Plan& pl, const uint8_t* frames, int B, int H, int W, float im_scale, float** rois_io,
+                           float** cls_io, float** box_io) {
+    fd_detector* d = pl.d;
+    const int R = d->prop.post_nms_top_n;
+    const bool keep = d->keep_taps;
+    float* staged = pl.buf(NB_STAGED, (size_t)B * H * W * 4);
+    if (!pl.dry) FD_TRY(stage_input_split(frames, B, H, W, d->norm, staged, pl.stream));
+    const int h1 = d->s_conv0.s.out_h(H), w1 = d->s_conv0.s.out_w(W);
+    float* c0 = pl.buf(NB_CONV0, (size_t)B * h1 * w1 * FILTERS[0]);
+    if (!pl.dry) {
+        SplitConvOut o;
+        o.y32 = c0;
+        FD_TRY(split_conv_forward(d->s_conv0, staged, B, H, W, nullptr, o, pl.stream));
+    }
+    pl.tap("conv0", c0, B, h1, w1, FILTERS[0]);
+    int h = (h1 + 2 - 3) / 2 + 1, w = (w1 + 2 - 3) / 2 + 1;
+    size_t xmax = (size_t)B * h * w * FILTERS[0];
+    {
+        int hh = h, ww = w;
+        for (int s = 0; s < 3; ++s) {
+            if (s > 0) { hh = (hh + 2 - 3) / 2 + 1; ww = (ww + 2 - 3) / 2 + 1; }
+            const size_t v = (size_t)B * hh * ww * FILTERS[s + 1];
+            if (v > xmax) xmax = v;
+        }
+    }
+    float* xbuf[2] = {pl.buf(NB_XA, xmax), pl.buf(NB_XB, xmax)};
+    float* abuf[2] = {pl.buf(NB_ACT_A, xmax), pl.buf(NB_ACT_B, xmax)};
+    // max pool: float32 copy only for inspection; the first unit (projection shortcut) needs act only
+    if (!pl.dry)
+        FD_TRY(maxpool_3x3s2_split(c0, B, h1, w1, FILTERS[0], d->stage[0][0].bn1_scale, d->stage[0][0].bn1_shift,
+                                   keep ? xbuf[0] : nullptr, abuf[0], pl.stream));
+    if (keep) pl.tap("pool0", xbuf[0], B, h, w, FILTERS[0]);
+    int cur = 0;
+    const float* xraw = nullptr;           // raw input of the next unit (NULL when it does not need one)
+    for (int s = 0; s < 3; ++s)
+        for (size_t u = 0; u < d->stage[s].size(); ++u) {
+            char name[32];
+            snprintf(name, sizeof(name), "stage%d_unit%d", s + 1, (int)u + 1);
+            const bool last = (s == 2 && u + 1 == d->stage[s].size());
+            const Unit* next = last ? nullptr : (u + 1 < d->stage[s].size() ? &d->stage[s][u + 1] : &d->stage[s + 1][0]);
+            // the raw sum is needed by an identity-shortcut successor, by ROI pooling, or for inspection
+            const bool want32 = last || keep || (next && !next->has_sc);
+            float* y32 = want32 ? xbuf[cur ^ 1] : nullptr;
+            FD_TRY(run_unit_split(pl, d->stage[s][u], name, abuf[cur], d->stage[s][u].has_sc ? nullptr : xraw, B, h, w,
+                                  y32, abuf[cur ^ 1], next ? next->bn1_scale : nullptr,
+                                  next ? next->bn1_shift : nullptr, &h, &w));
+            xraw = y32;
+            cur ^= 1;
+        }
+    const float* feat = xbuf[cur];
+    const void* feat_split = abuf[cur];    // split of the raw feature map (no BatchNorm): the RPN's input
+    pl.tap("feat", feat, B, h, w, FILTERS[3]);
+    const int fh = h, fw = w;
+    const int A = d->prop.num_ratios * d->prop.num_scales;
+    float* hid = pl.buf(NB_RPN_HID, (size_t)B * fh * fw * 512);
+    float* rout = pl.buf(NB_RPN_OUT, (size_t)B * fh * fw * 6 * A);
+    if (!pl.dry) {
+        SplitConvOut o1, o2;
+        o1.ysplit = hid;
+        o2.y32 = rout;
+        FD_TRY(split_conv_forward(d->s_rpn_conv, feat_split, B, fh, fw, nullptr, o1, pl.stream));
+        FD_TRY(split_conv_forward(d->s_rpn_out, hid, B, fh, fw, nullptr, o2, pl.stream));
+    }
+    pl.tap("rpn_out", rout, B, fh, fw, 6 * A);
+    float* rois = pl.buf(NB_ROIS, (size_t)B * R * 5);
+    float* roi_scores = pl.buf(NB_ROI_SCORES, (size_t)B * R);
+    int32_t* counts = reinterpret_cast<int32_t*>(pl.buf(NB_COUNTS, (size_t)B * 4));
+    if (!pl.dry) {
+        if (rois_io && *rois_io) rois = *rois_io;
+        RpnLayout lay;
+        lay.cls_batch = (long long)fh * fw * 6 * A; lay.cls_anchor = 1; lay.cls_h = (long long)fw * 6 * A;
+        lay.cls_w = 6 * A; lay.cls_bg_off = 0; lay.cls_fg_off = A;
+        lay.box_batch = lay.cls_batch; lay.box_chan = 1; lay.box_h = lay.cls_h; lay.box_w = lay.cls_w;
+        lay.box_off = 2 * A;
+        const float info[3] = {(float)H, (float)W, im_scale};
+        FD_TRY(proposal_run(d->ctx, &d->prop, rout, rout, lay, 1, nullptr, info, B, fh, fw, rois, roi_scores, counts,
+                            d->nan_flag, pl.stream));
+    }
+    pl.tap("rois", rois, B, R, 5, 1);
+    pl.tap("roi_scores", roi_scores, B, R, 1, 1);
+    const int N = B * R;
+    float* pooled = pl.buf(NB_POOLED, (size_t)N * POOLED * POOLED * FILTERS[3]);
+    const size_t x4 = (size_t)N * POOLED * POOLED * FILTERS[4];
+    float* x4buf[2] = {pl.buf(NB_X4A, x4), pl.buf(NB_X4B, x4)};
+    float* a4buf[2] = {pl.buf(NB_ACT_A, x4), pl.buf(NB_ACT_B, x4)};
+    if (!pl.dry) {
+        FD_TRY(roipool_nhwc(feat, B, FILTERS[3], fh, fw, rois, N, POOLED, POOLED, 1.0f / 16.0f, pooled, pl.stream));
+        // feat_split lives in one of the act buffers and is no longer needed: reuse them for stage 4
+        FD_TRY(to_split(pooled, (long long)N * POOLED * POOLED, FILTERS[3], d->stage[3][0].bn1_scale,
+                        d->stage[3][0].bn1_shift, a4buf[0], pl.stream));
+    }
+    pl.tap("pooled", pooled, N, POOLED, POOLED, FILTERS[3]);
+    h = POOLED; w = POOLED;
+    cur = 0;
+    xraw = nullptr;
+    for (size_t u = 0; u < d->stage[3].size(); ++u) {
+        char name[32];
+        snprintf(name, sizeof(name), "stage4_unit%d", (int)u + 1);
+        const bool last = u + 1 == d->stage[3].size();
+        const Unit* next = last ? nullptr : &d->stage[3][u + 1];
+        FD_TRY(run_unit_split(pl, d->stage[3][u], name, a4buf[cur], d->stage[3][u].has_sc ? nullptr : xraw, N, h, w,
+                              x4buf[cur ^ 1], last ? nullptr : a4buf[cur ^ 1], next ? next->bn1_scale : nullptr,
+                              next ? next->bn1_shift : nullptr, &h, &w));
+        xraw = x4buf[cur ^ 1];
+        cur ^= 1;
+    }
+    const float* c4 = x4buf[cur];
+    float* flat = pl.buf(NB_FLAT, (size_t)N * FILTERS[4]);
+    float* cls = pl.buf(NB_CLS, (size_t)N * 2);
+    float* box = pl.buf(NB_BOX, (size_t)N * 8);
+    if (!pl.dry) {
+        if (cls_io && *cls_io) cls = *cls_io;
+        if (box_io && *box_io) box = *box_io;
+        FD_TRY(bn_relu_avgpool(c4, N, h * w, FILTERS[4], d->bn1_scale, d->bn1_shift, flat, pl.stream));
+        FD_TRY(fc_head(flat, N, FILTERS[4], d->w_cls, d->b_cls, d->w_box, d->b_box, cls, box, pl.stream));
+        if (rois_io) *rois_io = rois;
+        if (cls_io) *cls_io = cls;
+        if (box_io) *box_io = box;
+    }
+    pl.tap("flat", flat, N, FILTERS[4], 1, 1);
+    pl.tap("cls_prob", cls, N, 2, 1, 1);
+    pl.tap("bbox_pred", box, N, 8, 1, 1);
+    return FD_OK;
+}
+
 static int forward(fd_detector* d, const uint8_t* frames, int B, int H, int W, float im_scale, float** rois,
                    float** cls, float** box, hipStream_t stream) {
     FD_REQUIRE(d && frames, "forward: NULL argument");
@@ -391,7 +586,8 @@ static int forward(fd_detector* d, const uint8_t* frames, int B, int H, int W, f
     Plan pl;
     pl.d = d; pl.stream = stream; pl.dry = true;
     memset(pl.need, 0, sizeof(pl.need));
-    FD_TRY(run_graph(pl, frames, B, H, W, im_scale, nullptr, nullptr, nullptr));
+    const bool split = d->precision == FD_PRECISION_F16X3;
+    FD_TRY((split ? run_graph_split : run_graph)(pl, frames, B, H, W, im_scale, nullptr, nullptr, nullptr));
     for (int i = 0; i < NB_COUNT; ++i) {
         Buf& b = d->net[i];
         const size_t bytes = pl.need[i] * sizeof(float);
@@ -416,7 +612,7 @@ static int forward(fd_detector* d, const uint8_t* frames, int B, int H, int W, f
         for (void* p : d->tap_copies) (void)hipFree(p);
         d->tap_copies.clear();
     }
-    return run_graph(pl, frames, B, H, W, im_scale, rois, cls, box);
+    return (split ? run_graph_split : run_graph)(pl, frames, B, H, W, im_scale, rois, cls, box);
 }
 
 }  // namespace fd
@@ -466,6 +662,14 @@ int fd_detector_set_proposal(fd_detector* d, const fd_proposal_cfg* cfg) {
                "fd_detector_set_proposal: the anchor count is fixed by the weights");
     FD_REQUIRE(cfg->post_nms_top_n > 0, "fd_detector_set_proposal: post_nms_top_n must be > 0");
     d->prop = *cfg;
+    return FD_OK;
+}
+
+int fd_detector_set_precision(fd_detector* d, int precision) {
+    FD_REQUIRE(d, "fd_detector_set_precision: NULL detector");
+    FD_REQUIRE(precision == FD_PRECISION_F32 || precision == FD_PRECISION_F16X3,
+               "fd_detector_set_precision: unknown precision %d", precision);
+    d->precision = precision;
     return FD_OK;
 }
 

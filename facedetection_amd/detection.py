@@ -51,7 +51,7 @@ def load_model(model_path, epoch=0):
 class Detector:
     """Faster R-CNN face detector (ResNet-50 backbone) on one MI355X."""
 
-    def __init__(self, model_path, ctx=None, epoch=0, box_f64=True):
+    def __init__(self, model_path, ctx=None, epoch=0, box_f64=True, precision="f16x3"):
         config.TEST.RPN_MIN_SIZE = 50            # detection.py:27
         self.device = _device_of(ctx)
         self.ctx = ctx
@@ -74,6 +74,15 @@ class Detector:
             _lib.check(self._lib.fd_detector_create(self._rt.handle, arr, len(params), C.byref(self._cfg),
                                                     C.byref(handle)))
             self._h = handle
+            self.set_precision(precision)
+
+    def set_precision(self, precision):
+        """"f32": float32 operands on the fp32 matrix cores.  "f16x3" (default): exact two-way
+        fp16 split of both operands, three f16 MFMAs per product, float32 accumulate --
+        float32-grade results, several times faster."""
+        code = {"f32": 0, "f16x3": 1}[precision]
+        _lib.check(self._lib.fd_detector_set_precision(self._h, code))
+        self.precision = precision
 
     def _proposal_cfg(self):
         # values are read from the global config when the detector is built or re-configured,

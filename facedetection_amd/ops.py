@@ -107,7 +107,8 @@ def postprocess(rois, scores, bbox_deltas, im_shape, thresh=0.8, nms_thresh=0.3,
     return out.cpu().numpy() if as_np else out
 
 
-def conv2d(x, weight, stride=1, pad=0, bias=None, pre_scale=None, pre_shift=None, relu=False, residual=None):
+def conv2d(x, weight, stride=1, pad=0, bias=None, pre_scale=None, pre_shift=None, relu=False, residual=None,
+           precision="f32"):
     """``mx.sym.Convolution`` fused with its neighbours (see fd_conv2d in facedet.h).
 
     x [B,H,W,Cin] channels-last, weight [Cout,Cin,kh,kw] (MXNet layout); returns y [B,Ho,Wo,Cout].
@@ -123,9 +124,10 @@ def conv2d(x, weight, stride=1, pad=0, bias=None, pre_scale=None, pre_shift=None
     dev = lambda a: None if a is None else runtime.to_device(a, torch.float32)
     xd, wd, bd, sd, hd, rd = dev(x), dev(weight), dev(bias), dev(pre_scale), dev(pre_shift), dev(residual)
     y = runtime.empty((B, Ho, Wo, Cout), torch.float32)
-    _lib.check(_lib.lib().fd_conv2d(ctx.handle, runtime.ptr(xd), B, H, W, Cin, runtime.ptr(wd), Cout, kh, kw,
-                                    int(stride), int(pad), runtime.ptr(bd), runtime.ptr(sd), runtime.ptr(hd),
-                                    1 if relu else 0, runtime.ptr(rd), runtime.ptr(y), runtime.stream_ptr()))
+    fn = _lib.lib().fd_conv2d if precision == "f32" else _lib.lib().fd_conv2d_f16x3
+    _lib.check(fn(ctx.handle, runtime.ptr(xd), B, H, W, Cin, runtime.ptr(wd), Cout, kh, kw,
+                  int(stride), int(pad), runtime.ptr(bd), runtime.ptr(sd), runtime.ptr(hd),
+                  1 if relu else 0, runtime.ptr(rd), runtime.ptr(y), runtime.stream_ptr()))
     return y.cpu().numpy() if as_np else y
 
 

@@ -154,6 +154,13 @@ int fd_conv2d(fd_ctx* ctx, const float* x_nhwc, int batch, int height, int width
               int cout, int kh, int kw, int stride, int pad, const float* bias, const float* pre_scale,
               const float* pre_shift, int relu, const float* residual, float* y_nhwc, void* stream);
 
+/* The same operator with split-precision arithmetic (FD_PRECISION_F16X3, see below); cout must be a
+ * multiple of 8.  Reads the weights back to the host to choose their scale: synchronous. */
+int fd_conv2d_f16x3(fd_ctx* ctx, const float* x_nhwc, int batch, int height, int width, int cin,
+                    const float* w_oihw, int cout, int kh, int kw, int stride, int pad, const float* bias,
+                    const float* pre_scale, const float* pre_shift, int relu, const float* residual,
+                    float* y_nhwc, void* stream);
+
 /* Detector ------------------------------------------------------------------------------
  * Detector.__init__ (detection.py:26-31): takes the checkpoint's tensors by their MXNet names
  * (arg_params and aux_params of `mxnet-face-fr50`: conv0_weight, bn0_gamma, bn0_moving_mean,
@@ -170,6 +177,17 @@ typedef struct fd_param {
 int fd_detector_create(fd_ctx* ctx, const fd_param* params, int n_params, const fd_proposal_cfg* cfg,
                        fd_detector** out);
 void fd_detector_destroy(fd_detector* det);
+/* Arithmetic of the convolutions.  Both accumulate in float32 on the matrix cores.
+ *   FD_PRECISION_F32   float32 operands (v_mfma_f32_32x32x2_f32): an fmaf chain.
+ *   FD_PRECISION_F16X3 every float32 operand is split exactly into two fp16 numbers
+ *                      (hi + lo, ~22 significant bits) and each product is formed as
+ *                      hi*hi + hi*lo + lo*hi on the f16 matrix cores: float32-grade results
+ *                      (same error level against a float64 reference) at 16/3 of the rate.
+ *                      Activations are clamped to the fp16 range (+-65504).  Default. */
+#define FD_PRECISION_F32 0
+#define FD_PRECISION_F16X3 1
+int fd_detector_set_precision(fd_detector* det, int precision);
+
 /* Replaces the proposal settings (the reference mutates `config` and rebuilds the symbol). */
 int fd_detector_set_proposal(fd_detector* det, const fd_proposal_cfg* cfg);
 

@@ -25,10 +25,10 @@ def params():
     return synthetic_params(0)
 
 
-@pytest.fixture(scope="module")
-def detector(params):
+@pytest.fixture(scope="module", params=["f16x3", "f32"])
+def detector(params, request):
     from facedetection_amd.detection import Detector
-    det = Detector(params, 0)
+    det = Detector(params, 0, precision=request.param)
     yield det
     det.close()
 
@@ -55,8 +55,9 @@ CONV_CASES = [
 ]
 
 
+@pytest.mark.parametrize("precision", ["f32", "f16x3"])
 @pytest.mark.parametrize("case", CONV_CASES, ids=lambda c: "x".join(str(v) for v in c[:8]) + "-" + c[8])
-def test_conv2d_vs_float64(ops, case):
+def test_conv2d_vs_float64(ops, case, precision):
     B, H, W, Cin, Cout, k, stride, pad, extras = case
     rng = np.random.default_rng(hash(case[:8]) % (2 ** 31))
     x = rng.normal(0, 1, (B, H, W, Cin)).astype(np.float32)
@@ -67,7 +68,7 @@ def test_conv2d_vs_float64(ops, case):
     Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
     res = rng.normal(0, 1, (B, Ho, Wo, Cout)).astype(np.float32) if "res" in extras else None
     y = ops.conv2d(x, w, stride=stride, pad=pad, bias=bias, pre_scale=ps, pre_shift=ph, relu="relu" in extras,
-                   residual=res)
+                   residual=res, precision=precision)
     xt = torch.from_numpy(x).double().permute(0, 3, 1, 2)
     if ps is not None:
         xt = F.relu(xt * torch.from_numpy(ps).double()[None, :, None, None] + torch.from_numpy(ph).double()[None, :, None, None])
