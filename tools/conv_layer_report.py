@@ -45,7 +45,7 @@ def layer_list(B, H=1080, W=1920, R=10):
 def main():
     path = sys.argv[1]
     B = int(sys.argv[2]) if len(sys.argv) > 2 else 8
-    rows = [r for r in csv.DictReader(open(path)) if "conv_igemm" in r["Kernel_Name"]]
+    rows = [r for r in csv.DictReader(open(path)) if "conv_igemm" in r["Kernel_Name"] or "conv_split_kernel" in r["Kernel_Name"]]
     layers = layer_list(B)
     last = rows[-len(layers):]
     tot = totf = 0.0
