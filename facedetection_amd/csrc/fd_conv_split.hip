@@ -263,6 +263,240 @@ __global__ __launch_bounds__(256, 2) void conv_split_kernel(SplitKArgs a) {
     }
 }
 
+// ---------------------------------------------------------------------------------
+// Direct-to-LDS variant (everything but the stem).  Both operand tiles are fetched with
+// `buffer_load_dwordx4 ... lds`: no staging registers, no ds_write, and padding taps / rows
+// beyond M are zero-filled by the buffer's range check (their offset is pushed out of range).
+// One wave instruction fills 8 rows x 128 B of the LDS image contiguously, so rows cannot be
+// padded; instead the 16-byte chunk c of row r is stored at chunk position c ^ ((r >> 1) & 7),
+// which makes the fragment reads (16 lanes, 16 distinct rows, same chunk) conflict-free.  The
+// permutation is applied on the global source address of each lane and undone when reading.
+template <int BM, int BN>
+__global__ __launch_bounds__(256, 2) void conv_split_glds_kernel(SplitKArgs a, unsigned x_bytes, unsigned w_bytes) {
+#if defined(__HIP_DEVICE_COMPILE__)   // buffer-resource builtins exist in device code only; the host pass needs just the stub
+    constexpr int GA = BM / 32, GB = BN / 32;   // 8-row groups per wave per K-step
+    constexpr int MT = BM / 64, NT = BN / 64;
+    constexpr int STAGE = (BM + BN) * 32;        // dwords per pipeline stage
+    constexpr int WN = BN / 2;
+    constexpr int LDC = WN + 4;
+    constexpr int EPI = 4 * 32 * LDC;            // epilogue staging, dwords
+    constexpr int SMEM = (2 * STAGE > EPI) ? 2 * STAGE : EPI;
+    __shared__ __attribute__((aligned(16))) float smem[SMEM];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    int wgid;
+    {
+        const int nwg = gridDim.x, bid = blockIdx.x;
+        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+        wgid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    }
+    const int tile_n = wgid % a.tiles_n, tile_m = wgid / a.tiles_n;
+
+    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, w_bytes, 0x00020000);
+    constexpr unsigned OOB = 0x80000000u;        // beyond any tensor this kernel is launched for
+
+    // this lane's row inside an 8-row group and the chunk position it fills
+    const int lrow = lane >> 3, lpos = lane & 7;
+    int hi0[GA], wi0[GA];
+    unsigned abase[GA];                          // byte offset of the row's window origin (+ its chunk)
+    bool mval[GA];
+#pragma unroll
+    for (int i = 0; i < GA; ++i) {
+        const int row = (wave + 4 * i) * 8 + lrow;                  // row inside the tile
+        const int chunk = lpos ^ ((row >> 1) & 7);
+        const int m = tile_m * BM + row;
+        mval[i] = m < a.M;
+        const int mm = mval[i] ? m : 0;
+        const int hw = a.Ho * a.Wo;
+        const int img = mm / hw;
+        const int rem = mm - img * hw;
+        const int ho = rem / a.Wo;
+        const int wo = rem - ho * a.Wo;
+        hi0[i] = ho * a.stride - a.pad;
+        wi0[i] = wo * a.stride - a.pad;
+        abase[i] = (unsigned)(((img * a.H + hi0[i]) * a.W + wi0[i]) * a.Cin * 4 + chunk * 16);
+    }
+    unsigned bbase[GB];
+#pragma unroll
+    for (int i = 0; i < GB; ++i) {
+        const int row = (wave + 4 * i) * 8 + lrow;
+        const int chunk = lpos ^ ((row >> 1) & 7);
+        bbase[i] = (unsigned)((tile_n * BN + row) * a.K * 4 + chunk * 16);
+    }
+    int kh = 0, kw = 0, coff = 0;
+    const int nk = a.K / SBK;
+
+#define FD_ISSUE(KT, STG)                                                                         \
+    do {                                                                                          \
+        const unsigned toff_ = (unsigned)(((kh * a.W + kw) * a.Cin + coff) * 4);                  \
+        float* sa_ = smem + (STG) * STAGE;                                                        \
+        _Pragma("unroll") for (int i = 0; i < GA; ++i) {                                          \
+            const int hi_ = hi0[i] + kh, wi_ = wi0[i] + kw;                                       \
+            const bool ok_ = mval[i] && (unsigned)hi_ < (unsigned)a.H && (unsigned)wi_ < (unsigned)a.W; \
+            const unsigned vo_ = ok_ ? abase[i] + toff_ : OOB;                                    \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(                                             \
+                xr, (__attribute__((address_space(3))) void*)(sa_ + (wave + 4 * i) * 256), 16, vo_, 0, 0, 0); \
+        }                                                                                         \
+        _Pragma("unroll") for (int i = 0; i < GB; ++i)                                            \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(                                             \
+                wr, (__attribute__((address_space(3))) void*)(sa_ + BM * 32 + (wave + 4 * i) * 256), 16, \
+                bbase[i] + (unsigned)(KT) * 128u, 0, 0, 0);                                       \
+        coff += SBK;                                                                              \
+        if (coff >= a.Cin) {                                                                      \
+            coff = 0;                                                                             \
+            if (++kw == a.KW) { kw = 0; ++kh; }                                                   \
+        }                                                                                         \
+    } while (0)
+
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NT; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+
+    // fragment addressing: row R (R & 31 == lane & 31 for every tile of this wave), chunk
+    // (part * 4 + kg * 2 + half) stored at position chunk ^ ((R >> 1) & 7)
+    const int frow = lane & 31, fh = lane >> 5;
+    const int sw = (frow >> 1) & 7;
+    const int a_row = (wm * (BM / 2) + frow) * 32;
+    const int b_row = (BM + wn * (BN / 2) + frow) * 32;
+
+    FD_ISSUE(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nk) FD_ISSUE(kt + 1, cur ^ 1);
+        const float* st = smem + cur * STAGE;
+#pragma unroll
+        for (int kg = 0; kg < 2; ++kg) {
+            const int ph = ((kg * 2 + fh) ^ sw) * 4, pl = ((4 + kg * 2 + fh) ^ sw) * 4;
+            f16x8 ah[MT], al[MT], bh[NT], bl[NT];
+#pragma unroll
+            for (int mi = 0; mi < MT; ++mi) {
+                ah[mi] = *reinterpret_cast<const f16x8*>(st + a_row + mi * 32 * 32 + ph);
+                al[mi] = *reinterpret_cast<const f16x8*>(st + a_row + mi * 32 * 32 + pl);
+            }
+#pragma unroll
+            for (int ni = 0; ni < NT; ++ni) {
+                bh[ni] = *reinterpret_cast<const f16x8*>(st + b_row + ni * 32 * 32 + ph);
+                bl[ni] = *reinterpret_cast<const f16x8*>(st + b_row + ni * 32 * 32 + pl);
+            }
+#pragma unroll
+            for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < NT; ++ni) {
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[mi], bh[ni], acc[mi][ni], 0, 0, 0);
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mi], bl[ni], acc[mi][ni], 0, 0, 0);
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mi], bh[ni], acc[mi][ni], 0, 0, 0);
+                }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+#undef FD_ISSUE
+
+    // epilogue (same as the register-staged kernel; the staging slice lives at the start of smem)
+    constexpr int L8 = WN / 8;
+    constexpr int RPP = 64 / L8;
+    constexpr int PASSES = 32 / RPP;
+    float* Cs = smem + wave * (32 * LDC);
+    const int erow = lane / L8, ecol = (lane % L8) * 8;
+    const int gcol = tile_n * BN + wn * WN + ecol;
+    const bool col_ok = gcol < a.Cout;
+    float bias_v[NT];
+#pragma unroll
+    for (int ni = 0; ni < NT; ++ni) {
+        const int col = tile_n * BN + wn * WN + ni * 32 + (lane & 31);
+        bias_v[ni] = (a.bias && col < a.Cout) ? a.bias[col] : 0.f;
+    }
+    f32x4 ps0 = {1.f, 1.f, 1.f, 1.f}, ps1 = ps0, pt0 = {0.f, 0.f, 0.f, 0.f}, pt1 = pt0;
+    const bool post = a.ysplit && a.post_scale && col_ok;
+    if (post) {
+        ps0 = *reinterpret_cast<const f32x4*>(a.post_scale + gcol);
+        ps1 = *reinterpret_cast<const f32x4*>(a.post_scale + gcol + 4);
+        pt0 = *reinterpret_cast<const f32x4*>(a.post_shift + gcol);
+        pt1 = *reinterpret_cast<const f32x4*>(a.post_shift + gcol + 4);
+    }
+#pragma unroll
+    for (int mi = 0; mi < MT; ++mi) {
+        const int grow0 = tile_m * BM + wm * (BM / 2) + mi * 32;
+        f32x4 res0[PASSES], res1[PASSES];
+        if (a.res) {
+#pragma unroll
+            for (int ps = 0; ps < PASSES; ++ps) {
+                const int row = grow0 + ps * RPP + erow;
+                res0[ps] = f32x4{0.f, 0.f, 0.f, 0.f};
+                res1[ps] = res0[ps];
+                if (row < a.M && col_ok) {
+                    const float* rp = a.res + (size_t)row * a.Cout + gcol;
+                    res0[ps] = *reinterpret_cast<const f32x4*>(rp);
+                    res1[ps] = *reinterpret_cast<const f32x4*>(rp + 4);
+                }
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int ni = 0; ni < NT; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float v = acc[mi][ni][r] * a.w_inv_scale + bias_v[ni];
+                if (a.relu) v = fmaxf(v, 0.f);
+                Cs[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * LDC + ni * 32 + (lane & 31)] = v;
+            }
+        __syncthreads();
+#pragma unroll
+        for (int ps = 0; ps < PASSES; ++ps) {
+            const int lrow2 = ps * RPP + erow;
+            const int row = grow0 + lrow2;
+            f32x4 v0 = *reinterpret_cast<const f32x4*>(&Cs[lrow2 * LDC + ecol]);
+            f32x4 v1 = *reinterpret_cast<const f32x4*>(&Cs[lrow2 * LDC + ecol + 4]);
+            if (a.res) { v0 += res0[ps]; v1 += res1[ps]; }
+            if (row < a.M && col_ok) {
+                if (a.y32) {
+                    float* yp = a.y32 + (size_t)row * a.Cout + gcol;
+                    *reinterpret_cast<f32x4*>(yp) = v0;
+                    *reinterpret_cast<f32x4*>(yp + 4) = v1;
+                }
+                if (a.ysplit) {
+                    if (post) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            v0[j] = fmaxf(v0[j] * ps0[j] + pt0[j], 0.f);
+                            v1[j] = fmaxf(v1[j] * ps1[j] + pt1[j], 0.f);
+                        }
+                    }
+                    f16x8 hi, lo;
+                    split8(v0, v1, hi, lo);
+                    uint8_t* sp = a.ysplit + (size_t)row * a.Cout * 4 + split_offset(gcol);
+                    *reinterpret_cast<f16x8*>(sp) = hi;
+                    *reinterpret_cast<f16x8*>(sp + 64) = lo;
+                }
+            }
+        }
+    }
+#endif
+}
+
+template <int BM, int BN>
+static int launch_split_glds(const SplitKArgs& a, size_t x_bytes, size_t w_bytes, hipStream_t stream) {
+    static const std::string name = std::string("conv_split_") + std::to_string(BM) + "x" + std::to_string(BN);
+    ProfScope scope(stream, name.c_str(), 2.0 * a.M * a.Cout * (double)a.K,
+                    (double)a.H * a.W * (a.M / ((double)a.Ho * a.Wo)) * 4.0 * a.Cin + 4.0 * a.Cout * (double)a.K +
+                        4.0 * a.M * a.Cout * ((a.res ? 1.0 : 0.0) + (a.y32 ? 1.0 : 0.0) + (a.ysplit ? 1.0 : 0.0)));
+    SplitKArgs k = a;
+    const int tiles_m = ceil_div(a.M, BM);
+    k.tiles_n = ceil_div(a.Cout, BN);
+    hipLaunchKernelGGL((conv_split_glds_kernel<BM, BN>), dim3(tiles_m * k.tiles_n), dim3(256), 0, stream, k,
+                       (unsigned)x_bytes, (unsigned)w_bytes);
+    FD_LAUNCH_CHECK();
+    return FD_OK;
+}
+
 template <int BM, int BN, bool STEM>
 static int launch_split(const SplitKArgs& a, hipStream_t stream) {
     static const std::string name =
@@ -304,6 +538,14 @@ int split_conv_forward(const SplitConvParams& p, const void* x_split, int batch,
     if (stem) return launch_split<128, 64, true>(a, stream);
     const long long t128 = (long long)ceil_div(a.M, 128) * ceil_div(s.cout, 128);
     const long long t12864 = (long long)ceil_div(a.M, 128) * ceil_div(s.cout, 64);
+    // the direct-to-LDS kernels address both tensors with 32-bit byte offsets below 2^31
+    const size_t x_bytes = (size_t)batch * h * w * s.cin * 4, w_bytes = s.packed_floats() * 4;
+    const bool glds = x_bytes < (1ull << 31) && w_bytes < (1ull << 31);
+    if (glds) {
+        if (s.cout > 64 && t128 >= 384) return launch_split_glds<128, 128>(a, x_bytes, w_bytes, stream);
+        if (t12864 >= 384) return launch_split_glds<128, 64>(a, x_bytes, w_bytes, stream);
+        return launch_split_glds<64, 64>(a, x_bytes, w_bytes, stream);
+    }
     if (s.cout > 64 && t128 >= 384) return launch_split<128, 128, false>(a, stream);
     if (t12864 >= 384) return launch_split<128, 64, false>(a, stream);
     return launch_split<64, 64, false>(a, stream);

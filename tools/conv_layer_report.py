@@ -45,7 +45,7 @@ def layer_list(B, H=1080, W=1920, R=10):
 def main():
     path = sys.argv[1]
     B = int(sys.argv[2]) if len(sys.argv) > 2 else 8
-    rows = [r for r in csv.DictReader(open(path)) if "conv_igemm" in r["Kernel_Name"] or "conv_split_kernel" in r["Kernel_Name"]]
+    rows = [r for r in csv.DictReader(open(path)) if "conv_igemm" in r["Kernel_Name"] or "conv_split_" in r["Kernel_Name"]]
     layers = layer_list(B)
     last = rows[-len(layers):]
     tot = totf = 0.0
@@ -58,7 +58,7 @@ def main():
         g = groups.setdefault(kind, [0.0, 0.0])
         g[0] += us
         g[1] += L[4]
-        tile = r["Kernel_Name"].split("<")[1].split(">")[0]
+        tile = r["Kernel_Name"].split("<")[1].split(">")[0] + (" glds" if "glds" in r["Kernel_Name"] else "")
         print("%-9s M=%8d N=%5d K=%5d %9.1f us %7.1f TF  tile %s" % (L[0], L[1], L[2], L[3], us, L[4] / us / 1e6, tile))
     print("total %.1f us for %d frames = %.2f ms/frame, %.1f TF" % (tot, B, tot / B / 1e3, totf / tot / 1e6))
     for k, (us, f) in sorted(groups.items(), key=lambda kv: -kv[1][0]):
