@@ -45,6 +45,25 @@ def make_frames(n, device, seed):
     return out
 
 
+def pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (FETCH_SIZE and
+    WRITE_SIZE, separate runs of this benchmark at the same micro-batch; profiles/*pmc_traffic.json),
+    or None when no pass covers it.  Counters cannot be read from inside this process."""
+    import glob
+    import re
+    m = re.match(r"conv_(split|igemm)_(\d+)x(\d+)", kernel)
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic.json")))
+    if not m or not files or kernel.endswith("_stem"):
+        return None, None
+    want = "<%s, %s>" % (m.group(2), m.group(3))
+    with open(files[-1]) as f:
+        table = json.load(f)["kernels"]
+    for name, row in table.items():
+        if want in name and ("split_glds" in name) == (m.group(1) == "split"):
+            return row["hbm_bytes_per_launch"], os.path.basename(files[-1])
+    return None, None
+
+
 def cpu_baseline(budget_s=15.0):
     """The CPU oracle (torch-CPU float32 port of the same pipeline) on 1080p frames, on this
     host's cores: at least 2 frames, more until the time budget is used."""
@@ -160,9 +179,12 @@ def main():
             # ALGORITHMIC FLOP/s on that path is the dense f16 MFMA peak / 3
             split = dom["kernel"].startswith("conv_split")
             peak = PEAK_F16_MATRIX_TFLOPS / 3.0 if split else PEAK_FP32_MATRIX_TFLOPS
+            traffic, traffic_src = pmc_traffic(dom["kernel"]) if B == 8 else (None, None)
             line["roofline"] = {
                 "bound": "mfma", "kernel": dom["kernel"], "achieved": round(tf, 3), "peak": round(peak, 1),
-                "unit": "TFLOP/s", "frac": round(tf / peak, 4), "traffic": None,
+                "unit": "TFLOP/s", "frac": round(tf / peak, 4), "traffic": traffic,
+                "traffic_note": ("HBM bytes per launch from %s; algorithmic bytes per launch %.0f"
+                                 % (traffic_src, dom["bytes"] / dom["launches"])) if traffic else None,
                 "peak_note": ("dense f16 MFMA peak 2500 TFLOP/s / 3 MFMAs per product" if split
                               else "dense fp32 MFMA peak"),
                 "launches": dom["launches"], "avg_launch_ms": round(dom["ms"] / dom["launches"], 4),
