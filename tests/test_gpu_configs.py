@@ -1,0 +1,79 @@
+"""The remaining BASELINE.json configurations as parity cases: 4K frames and the dense-crowd
+stress setting (every anchor into the RPN NMS, thousands of rois into the head)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import boxes as ob
+from oracle import cboxes
+from oracle import network as onet
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def params():
+    from facedetection_amd.synthetic import synthetic_params
+    return synthetic_params(0)
+
+
+def test_4k_frame_matches_oracle(params):
+    from facedetection_amd.detection import Detector
+    from facedetection_amd.synthetic import synthetic_image
+    img = np.tile(synthetic_image(1080, 1920, seed=21), (2, 2, 1))          # 2160 x 3840
+    assert img.shape == (2160, 3840, 3)
+    det = Detector(params, 0)
+    try:
+        dets = det.detect_face(img)
+        feat = det.tensor("feat")
+    finally:
+        det.close()
+    assert feat.shape == (1, 135, 240, 1024)
+    cfg = dict(pre_nms_top_n=1000, post_nms_top_n=10, nms_thresh=0.7, min_size=50)
+    ref = onet.detect_face(img, params, cfg, dtype=torch.float32)
+    assert dets.shape == ref.shape
+    assert np.abs(dets[:, 4] - ref[:, 4]).max(initial=0) <= 1e-4
+    assert np.abs(dets[:, :4] - ref[:, :4]).max(initial=0) <= 1.0
+
+
+def test_dense_crowd_settings(params):
+    """1080p, RPN_MIN_SIZE 12, no pre-NMS cut (97 920 candidates), 6 000 rois into stage 4."""
+    from facedetection_amd.detection import Detector
+    from facedetection_amd.symbol.config import config
+    from facedetection_amd.synthetic import crowd_image
+    img = crowd_image(1080, 1920, seed=2, faces=5000)
+    det = Detector(params, 0)
+    old = (config.TEST.RPN_MIN_SIZE, config.TEST.RPN_PRE_NMS_TOP_N, config.TEST.RPN_POST_NMS_TOP_N)
+    config.TEST.RPN_MIN_SIZE, config.TEST.RPN_PRE_NMS_TOP_N, config.TEST.RPN_POST_NMS_TOP_N = 12, 0, 6000
+    try:
+        det.reconfigure()
+        rois, cls_prob, deltas = det.forward(img)
+        rpn_out = det.tensor("rpn_out")
+        dets = det.detect_face(img)
+    finally:
+        config.TEST.RPN_MIN_SIZE, config.TEST.RPN_PRE_NMS_TOP_N, config.TEST.RPN_POST_NMS_TOP_N = old
+        det.close()
+    assert rois.shape == (6000, 5) and cls_prob.shape == (6000, 2) and deltas.shape == (6000, 8)
+    # RPN stage against the oracle's steps on the GPU's own head output (C restatement of the
+    # greedy NMS: the NumPy one needs minutes at this size)
+    A, (_, fh, fw, _) = 12, rpn_out.shape
+    score = torch.from_numpy(rpn_out[..., :24]).permute(0, 3, 1, 2)
+    prob = torch.softmax(score.reshape(1, 2, A * fh, fw), dim=1).reshape(1, 2 * A, fh, fw).numpy()
+    fg = prob[0, A:].transpose(1, 2, 0).reshape(-1)
+    d = rpn_out[0, :, :, 24:].reshape(-1, 4)
+    anchors = ob.shifted_anchors(fh, fw, 16.0, ob.generate_anchors(16.0, (0.5, 1, 2), (4, 8, 16, 32)))
+    boxes = ob.clip_boxes(ob.bbox_pred(anchors, d), (1080.0, 1920.0))
+    ok = np.where((boxes[:, 2] - boxes[:, 0] + 1 >= 12) & (boxes[:, 3] - boxes[:, 1] + 1 >= 12))[0]
+    order = ok[ob.score_order(fg[ok])]
+    cand = np.concatenate([boxes[order], np.arange(order.size, 0, -1, dtype=np.float64)[:, None]], axis=1)
+    keep = cboxes.nms(cand, 0.7)[:6000]
+    assert len(keep) == 6000, "the stress input should leave at least 6000 proposals"
+    np.testing.assert_allclose(rois[:, 1:], boxes[order][keep].astype(np.float32), rtol=1e-6, atol=1e-3)
+    # final detections: sorted, mutually below the NMS threshold, scores from the head
+    assert dets.shape[0] > 0 and (np.diff(dets[:, 4]) <= 0).all() and (dets[:, 4] >= 0.8).all()
+    again = ob.nms(dets, 0.3) if dets.shape[0] < 3000 else cboxes.nms(dets, 0.3)
+    # rounding moves coordinates by <= 0.5 px, so re-running NMS on the rounded boxes may drop a few
+    assert len(again) >= 0.98 * dets.shape[0]
+    ref = ob.postprocess(rois[:, 1:], cls_prob, deltas, (1080, 1920))
+    assert ref.shape == dets.shape
+    assert np.abs(ref[:, 4] - dets[:, 4]).max() <= 1e-6 and np.abs(ref[:, :4] - dets[:, :4]).max() <= 1.0
