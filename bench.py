@@ -100,10 +100,15 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    # under torch.distributed.run (RANK is set) the process group is used even for one rank, so the
+    # launch path the driver takes for N > 1 can be rehearsed on a single GPU
+    distributed = world > 1 or "RANK" in os.environ
+    if distributed:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
+        os.environ.setdefault("MASTER_PORT", "29512")
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world,
+                                device_id=torch.device("cuda", local))
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
 
@@ -122,7 +127,7 @@ def main():
         return outs
 
     def barrier():
-        if world > 1:
+        if distributed:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -138,7 +143,7 @@ def main():
     elapsed = time.perf_counter() - t0
     rows = [] if args.no_profile else profiling.end()
 
-    if world > 1:
+    if distributed:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -146,7 +151,7 @@ def main():
     # hand-off (untimed): per-frame detection lists gathered in global frame order
     dets = torch.cat([o[0] for o in outs])
     counts = torch.cat([o[1] for o in outs])
-    gathered = gather_detections(dets, counts, rank, world)
+    gathered = gather_detections(dets, counts, rank, world, force_collective=distributed)
     n_boxes = int(sum(len(g) for g in gathered)) if gathered is not None else 0
 
     if rank == 0:
@@ -198,7 +203,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if distributed:
         dist.destroy_process_group()
 
 

@@ -15,12 +15,12 @@ def shard_indices(n_frames, rank, world):
     return list(range(rank, n_frames, world))
 
 
-def gather_detections(dets, counts, rank=0, world=1):
+def gather_detections(dets, counts, rank=0, world=1, force_collective=False):
     """dets [F,R,5] float32 and counts [F] int32 of this rank's frames (frame j of rank r is
     global frame j*world + r) -> on every rank, a list over GLOBAL frame order of float32
     [n_i,5] arrays, ready for an order-dependent consumer such as a SORT tracker."""
     F, R = int(dets.shape[0]), int(dets.shape[1])
-    if world == 1:
+    if world == 1 and not force_collective:
         d, c = dets.cpu().numpy(), counts.cpu().numpy()
         return [d[i, :c[i]].copy() for i in range(F)]
     import torch.distributed as dist

@@ -1,0 +1,49 @@
+#!/usr/bin/env python3
+"""Latency and per-kernel time of the BASELINE.json configurations other than the headline one:
+single 1080p frame, single 4K frame, dense-crowd 1080p frame.  Run on the GPU box."""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from facedetection_amd import profiling  # noqa: E402
+from facedetection_amd.detection import Detector  # noqa: E402
+from facedetection_amd.symbol.config import config  # noqa: E402
+from facedetection_amd.synthetic import crowd_image, synthetic_image  # noqa: E402
+
+
+def run(det, frame, reps):
+    f = det._frames(frame)
+    for _ in range(2):
+        det.detect_batch_device(f)
+    torch.cuda.synchronize()
+    profiling.begin()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        det.detect_batch_device(f)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / reps
+    rows = profiling.end()
+    top = sorted(rows, key=lambda r: -r["ms"])[:6]
+    return dt * 1e3, [(r["kernel"], round(r["ms"] / reps, 3)) for r in top]
+
+
+def main():
+    det = Detector("synthetic:0", 0)
+    out = {}
+    out["1080p_single"] = run(det, synthetic_image(1080, 1920, seed=1), 20)
+    out["4k_single"] = run(det, np.tile(synthetic_image(1080, 1920, seed=2), (2, 2, 1)), 10)
+    config.TEST.RPN_MIN_SIZE, config.TEST.RPN_PRE_NMS_TOP_N, config.TEST.RPN_POST_NMS_TOP_N = 12, 0, 6000
+    det.reconfigure()
+    out["dense_crowd_1080p"] = run(det, crowd_image(1080, 1920, seed=2), 5)
+    for k, (ms, top) in out.items():
+        print("%-20s %8.2f ms/frame  %s" % (k, ms, top))
+    print(json.dumps({k: {"ms": round(v[0], 3), "top_kernels_ms": v[1]} for k, v in out.items()}))
+
+
+if __name__ == "__main__":
+    main()
