@@ -165,19 +165,28 @@ int sort_pairs_u64(fd_ctx* ctx, uint64_t* ka, uint32_t* va, uint64_t* kb, uint32
 }
 
 // ---------------------------------------------------------------------------------
-// Bitmask NMS.
-// mask[seg][i][w] bit b == 1  <=>  candidate j = 64 w + b (j > i) is suppressed by i,
-// i.e. NOT (iou(i, j) <= thresh), with the reference's arithmetic:
+// Bitmask NMS, in row panels.
+// mask[seg][i - panel start][w] bit b == 1  <=>  candidate j = 64 w + b (j > i) is suppressed
+// by i, i.e. NOT (iou(i, j) <= thresh), with the reference's arithmetic:
 //   area = (x2 - x1 + 1) * (y2 - y1 + 1)
 //   iw = max(0, min(x2i, x2j) - max(x1i, x1j) + 1), ih likewise, inter = iw * ih
 //   iou = inter / (area_i + area_j - inter)
-// Only the upper triangle (w >= i / 64) is written and read.
+// Only the upper triangle (w >= i / 64) is written and read.  Candidates are processed in
+// panels of NMS_PANEL_CHUNKS * 64 rows: mask kernel, then the serial reduce for those rows,
+// which carries the `removed` bitmap and the keep count to the next panel through global
+// memory.  Once max_keep boxes are kept the remaining panels' kernels exit at once, so a
+// proposal stage that wants 6 000 of 100 000 candidates computes only the rows it needs, and
+// the mask buffer is one panel (<= 4096 x cap/8 bytes) instead of cap^2/8 bytes.
 // ---------------------------------------------------------------------------------
+constexpr int NMS_PANEL_CHUNKS = 64;
+
 template <typename T>
 __global__ __launch_bounds__(64) void nms_mask_kernel(const T* __restrict__ boxes, const int32_t* __restrict__ counters,
-                                                      int cap, int words, T thresh, uint64_t* __restrict__ mask) {
-    const int col = blockIdx.x, rowc = blockIdx.y, seg = blockIdx.z;
+                                                      int cap, int words, int chunk0, int panel_rows, int max_keep,
+                                                      T thresh, uint64_t* __restrict__ mask) {
+    const int col = chunk0 + blockIdx.x, rowc = chunk0 + blockIdx.y, seg = blockIdx.z;
     if (col < rowc) return;
+    if (max_keep > 0 && counters[seg * CNT_STRIDE + CNT_KEEP] >= max_keep) return;
     const int n = counters[seg * CNT_STRIDE + CNT_CAND];
     if (rowc * 64 >= n || col * 64 >= n) return;
     __shared__ T cb[64][5];
@@ -216,7 +225,7 @@ __global__ __launch_bounds__(64) void nms_mask_kernel(const T* __restrict__ boxe
         const T iou = inter / (area + cb[j][4] - inter);
         if (!(iou <= thresh)) bits |= 1ull << j;
     }
-    mask[((size_t)seg * cap + i) * words + col] = bits;
+    mask[((size_t)seg * panel_rows + (i - chunk0 * 64)) * words + col] = bits;
 }
 
 __device__ __forceinline__ uint64_t wave_uniform_u64(uint64_t v) {
@@ -225,29 +234,38 @@ __device__ __forceinline__ uint64_t wave_uniform_u64(uint64_t v) {
     return ((uint64_t)hi << 32) | lo;
 }
 
-// One workgroup per image walks the candidates in chunks of 64.  Wave 0 resolves the
+// One workgroup per image walks the panel's candidates in chunks of 64.  Wave 0 resolves a
 // chunk against its own diagonal mask words; then every thread ORs the rows of the kept
-// boxes into its share of the `removed` bitmap (LDS).
+// boxes into its share of the `removed` bitmap (LDS; saved to / restored from removed_g
+// between panels).
 constexpr int REDUCE_THREADS = 1024;
 __global__ __launch_bounds__(REDUCE_THREADS) void nms_reduce_kernel(const uint64_t* __restrict__ mask,
-                                                                   int32_t* __restrict__ counters, int cap, int words,
-                                                                   int max_keep, int32_t* __restrict__ keep) {
+                                                                   int32_t* __restrict__ counters,
+                                                                   uint64_t* __restrict__ removed_g, int cap, int words,
+                                                                   int chunk0, int panel_rows, int max_keep,
+                                                                   int32_t* __restrict__ keep) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     uint64_t* removed = reinterpret_cast<uint64_t*>(smem_raw);          // [words]
     uint64_t* s_kept = removed + words;                                  // [1]
     int* s_count = reinterpret_cast<int*>(s_kept + 1);                   // [1]
     const int seg = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+    const int count0 = counters[seg * CNT_STRIDE + CNT_KEEP];
+    if (max_keep > 0 && count0 >= max_keep) return;
     const int n = counters[seg * CNT_STRIDE + CNT_CAND];
     const int W = (n + 63) >> 6;
-    const uint64_t* segm = mask + (size_t)seg * cap * words;
+    if (chunk0 >= W) return;
+    const int cend = min(chunk0 + panel_rows / 64, W);
+    const uint64_t* segm = mask + (size_t)seg * panel_rows * words;
+    uint64_t* segr = removed_g + (size_t)seg * words;
     int32_t* segk = keep + (size_t)seg * cap;
-    for (int w = tid; w < W; w += REDUCE_THREADS) removed[w] = 0;
-    if (tid == 0) { *s_count = 0; *s_kept = 0; }
+    for (int w = chunk0 + tid; w < W; w += REDUCE_THREADS) removed[w] = (chunk0 == 0) ? 0ull : segr[w];
+    if (tid == 0) { *s_count = count0; *s_kept = 0; }
     __syncthreads();
-    for (int c = 0; c < W; ++c) {
+    for (int c = chunk0; c < cend; ++c) {
+        const int lrow0 = (c - chunk0) * 64;        // first row of the chunk inside the panel
         if (tid < 64) {
             const int i = c * 64 + lane;
-            const uint64_t diag = (i < n) ? segm[(size_t)i * words + c] : 0ull;
+            const uint64_t diag = (i < n) ? segm[(size_t)(lrow0 + lane) * words + c] : 0ull;
             const uint32_t dlo = (uint32_t)diag, dhi = (uint32_t)(diag >> 32);
             uint64_t rem = wave_uniform_u64(removed[c]);
             const int left = n - c * 64;
@@ -283,12 +301,13 @@ __global__ __launch_bounds__(REDUCE_THREADS) void nms_reduce_kernel(const uint64
             while (k) {
                 const int b = __ffsll((long long)k) - 1;
                 k &= k - 1;
-                acc |= segm[(size_t)(c * 64 + b) * words + w];
+                acc |= segm[(size_t)(lrow0 + b) * words + w];
             }
             removed[w] = acc;
         }
         __syncthreads();
     }
+    for (int w = cend + tid; w < W; w += REDUCE_THREADS) segr[w] = removed[w];
     if (tid == 0) {
         int count = *s_count;
         if (max_keep > 0 && count > max_keep) count = max_keep;
@@ -296,8 +315,8 @@ __global__ __launch_bounds__(REDUCE_THREADS) void nms_reduce_kernel(const uint64
     }
 }
 
-// Largest candidate count the bitmask path accepts: the mask is cap^2/8 bytes per image.
-constexpr long long NMS_MAX_CAND = 262144;
+// The `removed` bitmap of one image lives in LDS during the reduce: cap / 8 bytes.
+constexpr long long NMS_MAX_CAND = 480000;
 
 template <typename T>
 int nms_sorted(fd_ctx* ctx, const T* cand_boxes, int32_t* counters, int cap, int nseg, T thresh, int max_keep,
@@ -308,22 +327,30 @@ int nms_sorted(fd_ctx* ctx, const T* cand_boxes, int32_t* counters, int cap, int
         return FD_ERR_LIMIT;
     }
     const int words = ceil_div(cap, 64);
-    uint64_t* mask = nullptr;
-    FD_TRY(scratch_as(ctx, SLOT_NMS_MASK, (size_t)nseg * cap * words, &mask));
-    dim3 grid(words, words, nseg);
-    {
-        // upper-triangle mask: cap^2/16 bytes written; 4 box coordinates read per candidate
-        ProfScope scope(stream, "nms_mask", 0.0, (double)nseg * ((double)cap * cap / 16.0 + 4.0 * sizeof(T) * cap));
-        hipLaunchKernelGGL(nms_mask_kernel<T>, grid, dim3(64), 0, stream, cand_boxes, counters, cap, words, thresh,
-                           mask);
-        FD_LAUNCH_CHECK();
-    }
+    const int panel_chunks = words < NMS_PANEL_CHUNKS ? words : NMS_PANEL_CHUNKS;
+    const int panel_rows = panel_chunks * 64;
+    uint64_t *mask = nullptr, *removed_g = nullptr;
+    FD_TRY(scratch_as(ctx, SLOT_NMS_MASK, (size_t)nseg * panel_rows * words, &mask));
+    FD_TRY(scratch_as(ctx, SLOT_MISC2, (size_t)nseg * words, &removed_g));
     const size_t smem = (size_t)words * 8 + 16;
-    {
-        ProfScope scope(stream, "nms_reduce", 0.0, (double)nseg * (double)cap * cap / 16.0);
-        hipLaunchKernelGGL(nms_reduce_kernel, dim3(nseg), dim3(REDUCE_THREADS), smem, stream, mask, counters, cap,
-                           words, max_keep, keep);
-        FD_LAUNCH_CHECK();
+    for (int chunk0 = 0; chunk0 < words; chunk0 += panel_chunks) {
+        const int rows_here = (words - chunk0 < panel_chunks ? words - chunk0 : panel_chunks);
+        {
+            // upper-triangle part of this panel: rows x remaining columns / 8 bytes written
+            const double cols = (double)(words - chunk0) * 64.0;
+            ProfScope scope(stream, "nms_mask", 0.0,
+                            (double)nseg * (rows_here * 64.0 * cols / 8.0 * 0.5 + 4.0 * sizeof(T) * cols));
+            hipLaunchKernelGGL(nms_mask_kernel<T>, dim3(words - chunk0, rows_here, nseg), dim3(64), 0, stream,
+                               cand_boxes, counters, cap, words, chunk0, panel_rows, max_keep, thresh, mask);
+            FD_LAUNCH_CHECK();
+        }
+        {
+            ProfScope scope(stream, "nms_reduce", 0.0,
+                            (double)nseg * rows_here * 64.0 * (double)(words - chunk0) * 8.0 * 0.5);
+            hipLaunchKernelGGL(nms_reduce_kernel, dim3(nseg), dim3(REDUCE_THREADS), smem, stream, mask, counters,
+                               removed_g, cap, words, chunk0, panel_rows, max_keep, keep);
+            FD_LAUNCH_CHECK();
+        }
     }
     return FD_OK;
 }

@@ -98,6 +98,17 @@ def test_nms_vs_oracle_seeded(P, n, nc, dtype):
         np.testing.assert_array_equal(P.nms(dets, thr), ob.nms(dets, thr))
 
 
+@pytest.mark.parametrize("n,nc", [(100000, 1000), (300000, 300)])
+def test_nms_many_row_panels_vs_c_oracle(P, n, nc):
+    """Tens of row panels, the `removed` bitmap carried between them; index-exact against the
+    C restatement of the greedy loop (the NumPy one needs minutes at this size)."""
+    from oracle import cboxes
+    rng = np.random.default_rng(n + 1)
+    dets = rand_dets(rng, n, nc, lo=12.0, hi=40.0)
+    np.testing.assert_array_equal(np.asarray(P.nms(dets, 0.7), dtype=np.int64),
+                                  np.asarray(cboxes.nms(dets, 0.7), dtype=np.int64))
+
+
 def test_nms_many_equal_scores(P):
     rng = np.random.default_rng(9)
     dets = rand_dets(rng, 3000, 100)
