@@ -70,6 +70,8 @@ SIGNATURES = {
     "fd_resize_dims": (C.c_int, [C.c_int, C.c_int, C.c_double, C.c_double, c_i32p, c_i32p]),
     "fd_resize_u8": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, vp, C.c_int,
                                C.c_int, vp]),
+    "fd_crop_resize_pad": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp,
+                                     vp]),
     "fd_conv2d": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                             vp, vp, vp, C.c_int, vp, vp, vp]),
     "fd_conv2d_f16x3": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_int,

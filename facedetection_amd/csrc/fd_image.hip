@@ -64,6 +64,88 @@ __global__ __launch_bounds__(256) void resize_linear_u8_kernel(const uint8_t* __
     }
 }
 
+// ---------------------------------------------------------------------------------
+// Face crops for the recognition stage: the reference slices a padded box out of the frame
+// (code/common/Function.py:49-70) and later letterboxes every crop to a fixed size
+// (code/common/Function.py:95-113).  Here both happen in one launch for all boxes of a
+// frame: block z handles box z, every thread one destination pixel.
+//   rect:  (x1,y1,x2,y2) truncated to int; pad = round-half-even(side * 0.1) per direction;
+//          x1 = max(0, x1 - pad), x2 = min(W, x2 + pad), same for y (x2/y2 exclusive).
+//   scale: crop h/w > dest h/w ? dest_h / crop_h : dest_w / crop_w  (double);
+//          resized size = round-half-even(crop size * scale), centred, zero border.
+// ---------------------------------------------------------------------------------
+struct CropGeom {
+    int x1, y1, x2, y2;     // source rectangle in the frame
+    int rh, rw;             // size of the resized crop inside the tile
+    int top, left;          // its offset inside the tile
+    double inv_scale;       // source step per destination pixel
+    int area2;              // exact 2x reduction -> 2x2 average
+};
+
+__device__ __forceinline__ CropGeom crop_geom(const double* __restrict__ box, int H, int W, int dh, int dw) {
+    CropGeom g;
+    int x1 = (int)box[0], y1 = (int)box[1], x2 = (int)box[2], y2 = (int)box[3];
+    const int pw = (int)rint((double)(x2 - x1) * 0.1);
+    const int ph = (int)rint((double)(y2 - y1) * 0.1);
+    g.x1 = max(0, x1 - pw);
+    g.y1 = max(0, y1 - ph);
+    g.x2 = min(W, x2 + pw);
+    g.y2 = min(H, y2 + ph);
+    const int ch = g.y2 - g.y1, cw = g.x2 - g.x1;
+    g.rh = g.rw = g.top = g.left = 0;
+    g.inv_scale = 1.0;
+    g.area2 = 0;
+    if (ch <= 0 || cw <= 0) return g;
+    const double ratio_src = (double)ch / (double)cw, ratio_des = (double)dh / (double)dw;
+    const bool tall = ratio_src > ratio_des;
+    const double scale = tall ? (double)dh / (double)ch : (double)dw / (double)cw;
+    g.rh = (int)rint((double)ch * scale);
+    g.rw = (int)rint((double)cw * scale);
+    g.inv_scale = 1.0 / scale;
+    g.area2 = (g.inv_scale == 2.0 && ch % 2 == 0 && cw % 2 == 0) ? 1 : 0;
+    if (tall) g.left = (dw - g.rw) >> 1;      // arithmetic shift == Python's floor division
+    else g.top = (dh - g.rh) >> 1;
+    return g;
+}
+
+__global__ __launch_bounds__(256) void crop_resize_pad_kernel(const uint8_t* __restrict__ frame, int H, int W, int c,
+                                                             const double* __restrict__ boxes, int box_stride,
+                                                             uint8_t* __restrict__ tiles, int dh, int dw,
+                                                             int32_t* __restrict__ rects) {
+    const int ox = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int oy = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const int b = blockIdx.z;
+    const CropGeom g = crop_geom(boxes + (size_t)b * box_stride, H, W, dh, dw);
+    if (rects && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
+        rects[b * 4 + 0] = g.x1; rects[b * 4 + 1] = g.y1; rects[b * 4 + 2] = g.x2; rects[b * 4 + 3] = g.y2;
+    }
+    if (!tiles || ox >= dw || oy >= dh) return;
+    uint8_t* o = tiles + (((size_t)b * dh + oy) * dw + ox) * c;
+    const int ix = ox - g.left, iy = oy - g.top;
+    if (ix < 0 || iy < 0 || ix >= g.rw || iy >= g.rh) {
+        for (int k = 0; k < c; ++k) o[k] = 0;
+        return;
+    }
+    const int ch = g.y2 - g.y1, cw = g.x2 - g.x1;
+    const uint8_t* s = frame + ((size_t)g.y1 * W + g.x1) * c;          // crop origin; row pitch W * c
+    const size_t pitch = (size_t)W * c;
+    if (g.area2) {
+        const uint8_t* r0 = s + (size_t)(2 * iy) * pitch + (size_t)(2 * ix) * c;
+        const uint8_t* r1 = r0 + pitch;
+        for (int k = 0; k < c; ++k) o[k] = (uint8_t)((r0[k] + r0[c + k] + r1[k] + r1[c + k] + 2) >> 2);
+        return;
+    }
+    const Tap2 tx = linear_tap(ix, g.inv_scale, cw);
+    const Tap2 ty = linear_tap(iy, g.inv_scale, ch);
+    const uint8_t* r0 = s + (size_t)ty.s0 * pitch;
+    const uint8_t* r1 = s + (size_t)ty.s1 * pitch;
+    for (int k = 0; k < c; ++k) {
+        const int h0 = r0[tx.s0 * c + k] * tx.w0 + r0[tx.s1 * c + k] * tx.w1;
+        const int h1 = r1[tx.s0 * c + k] * tx.w0 + r1[tx.s1 * c + k] * tx.w1;
+        o[k] = (uint8_t)((((ty.w0 * (h0 >> 4)) >> 16) + ((ty.w1 * (h1 >> 4)) >> 16) + 2) >> 2);
+    }
+}
+
 }  // namespace fd
 
 extern "C" {
@@ -91,6 +173,24 @@ int fd_resize_u8(fd_ctx* ctx, const uint8_t* src, int batch, int src_h, int src_
     dim3 grid(fd::ceil_div(dst_w, 64), fd::ceil_div(dst_h, 4), batch);
     hipLaunchKernelGGL(fd::resize_linear_u8_kernel, grid, dim3(256), 0, fd::as_stream(stream), src, src_h, src_w,
                        channels, scale_x, scale_y, dst, dst_h, dst_w, area2);
+    FD_LAUNCH_CHECK();
+    return FD_OK;
+}
+
+int fd_crop_resize_pad(fd_ctx* ctx, const uint8_t* frame, int height, int width, int channels, const double* boxes,
+                       int box_stride, int n_boxes, int dst_h, int dst_w, uint8_t* tiles, int32_t* rects,
+                       void* stream) {
+    (void)ctx;
+    FD_REQUIRE(n_boxes >= 0 && box_stride >= 4, "fd_crop_resize_pad: bad box layout");
+    if (n_boxes == 0) return FD_OK;
+    FD_REQUIRE(boxes && (tiles || rects) && (frame || !tiles) && height > 0 && width > 0 && channels > 0 &&
+                   channels <= 4 && dst_h > 0 && dst_w > 0 && n_boxes <= 65535,
+               "fd_crop_resize_pad: bad arguments");
+    fd::ProfScope scope(fd::as_stream(stream), "crop_resize_pad", 0.0,
+                        2.0 * (double)n_boxes * channels * (double)dst_h * dst_w);
+    dim3 grid(tiles ? fd::ceil_div(dst_w, 64) : 1, tiles ? fd::ceil_div(dst_h, 4) : 1, n_boxes);
+    hipLaunchKernelGGL(fd::crop_resize_pad_kernel, grid, dim3(256), 0, fd::as_stream(stream), frame, height, width,
+                       channels, boxes, box_stride, tiles, dst_h, dst_w, rects);
     FD_LAUNCH_CHECK();
     return FD_OK;
 }

@@ -149,3 +149,43 @@ def resize_bilinear(im, fx, fy):
     if single:
         out = out[0]
     return out.cpu().numpy() if as_np else out
+
+
+def crop_resize_pad(frame, boxes, des_size=(112, 112), tiles=True):
+    """``Function.stick_boxes`` + ``Function.resize_pad`` (code/common/Function.py:49-70,95-113) for
+    all boxes of one uint8 frame [H,W,C] in one launch.  ``boxes`` [n,>=4] (x1,y1,x2,y2,...):
+    detections or tracker rows.  Returns (tiles uint8 [n,des_h,des_w,C], rects int32 [n,4]) as
+    NumPy arrays for a NumPy frame, device tensors otherwise; ``tiles=False`` computes the
+    rectangles only."""
+    as_np = not isinstance(frame, torch.Tensor)
+    f = runtime.to_device(frame, torch.uint8)
+    H, W, Cc = (int(v) for v in f.shape)
+    b = runtime.to_device(boxes if isinstance(boxes, torch.Tensor) else np.asarray(boxes, dtype=np.float64),
+                          torch.float64)
+    if b.dim() != 2 or b.shape[1] < 4:
+        raise ValueError("boxes must be [n, >=4]")
+    n = int(b.shape[0])
+    dh, dw = int(des_size[0]), int(des_size[1])
+    out = runtime.empty((n, dh, dw, Cc), torch.uint8) if tiles else None
+    rects = runtime.empty((n, 4), torch.int32)
+    ctx = runtime.context()
+    _lib.check(_lib.lib().fd_crop_resize_pad(ctx.handle, runtime.ptr(f), H, W, Cc, runtime.ptr(b), int(b.shape[1]), n,
+                                             dh, dw, runtime.ptr(out) if tiles else None, runtime.ptr(rects),
+                                             runtime.stream_ptr()))
+    if as_np:
+        return (out.cpu().numpy() if tiles else None), rects.cpu().numpy()
+    return out, rects
+
+
+def crop_rects(boxes, height, width):
+    """The padded, clamped slice bounds of ``Function.stick_boxes`` (code/common/Function.py:53-64)
+    for boxes [n,>=4] in a frame of the given size: (None, int32 [n,4] NumPy array)."""
+    b = runtime.to_device(boxes if isinstance(boxes, torch.Tensor) else np.asarray(boxes, dtype=np.float64),
+                          torch.float64)
+    n = int(b.shape[0])
+    rects = runtime.empty((n, 4), torch.int32)
+    ctx = runtime.context()
+    _lib.check(_lib.lib().fd_crop_resize_pad(ctx.handle, None, int(height), int(width), 3, runtime.ptr(b),
+                                             int(b.shape[1]), n, 1, 1, None, runtime.ptr(rects),
+                                             runtime.stream_ptr()))
+    return None, rects.cpu().numpy()

@@ -38,3 +38,10 @@ def gather_detections(dets, counts, rank=0, world=1, force_collective=False):
         for r in range(world):
             out.append(ds[r][j, :cs[r][j]].copy())
     return out
+
+
+def feed_tracker(tracker, dets_per_frame):
+    """Hand the gathered lists to an order-dependent consumer: ``tracker.update`` is called once
+    per frame in global frame order, empty frames included (the contract of
+    code/tracking/sort.py:185-193).  Returns the tracker's output per frame."""
+    return [tracker.update(d) for d in dets_per_frame]

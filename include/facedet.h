@@ -142,6 +142,21 @@ int fd_resize_dims(int src_h, int src_w, double fx, double fy, int* dst_h_host, 
 int fd_resize_u8(fd_ctx* ctx, const uint8_t* src, int batch, int src_h, int src_w, int channels, double fx,
                  double fy, uint8_t* dst, int dst_h, int dst_w, void* stream);
 
+/* Face crops ------------------------------------------------------------------------
+ * Function.stick_boxes (code/common/Function.py:49-70) followed by Function.resize_pad
+ * (code/common/Function.py:95-113) for every box of a frame, as the reference's video loop
+ * does between tracker and recogniser (code/data_processing/ProcessVideo.py:150,
+ * Function.py:381-382).  frame uint8 [height, width, channels] on the device; boxes float64
+ * [n_boxes, box_stride] on the device, columns 0..3 = x1, y1, x2, y2 (detections or tracker
+ * rows).  tiles uint8 [n_boxes, dst_h, dst_w, channels] receives the letterboxed crops;
+ * rects int32 [n_boxes, 4] (may be NULL) receives the padded, clamped slice bounds
+ * (x1, y1, x2, y2; x2 / y2 exclusive).  The reference draws a rectangle into the frame before
+ * slicing; that overlay is not reproduced.  An empty rectangle gives a black tile.  With
+ * tiles == NULL only the rectangles are computed. */
+int fd_crop_resize_pad(fd_ctx* ctx, const uint8_t* frame, int height, int width, int channels, const double* boxes,
+                       int box_stride, int n_boxes, int dst_h, int dst_w, uint8_t* tiles, int32_t* rects,
+                       void* stream);
+
 /* Convolution operator ---------------------------------------------------------------
  * mx.sym.Convolution as used throughout symbol/faster_rcnn.py:33-52,85-89,131, with the
  * neighbouring BatchNorm / Activation / elementwise-add operators it is fused with here:
