@@ -72,6 +72,10 @@ SIGNATURES = {
                                C.c_int, vp]),
     "fd_crop_resize_pad": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp,
                                      vp]),
+    "fd_resize_cvt_u8": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int, vp,
+                                   C.c_int, C.c_int, vp]),
+    "fd_detect_scaled": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, vp, vp, vp, vp,
+                                   vp]),
     "fd_conv2d": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                             vp, vp, vp, C.c_int, vp, vp, vp]),
     "fd_conv2d_f16x3": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_int,

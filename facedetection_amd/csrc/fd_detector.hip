@@ -615,6 +615,14 @@ static int forward(fd_detector* d, const uint8_t* frames, int B, int H, int W, f
     return (split ? run_graph_split : run_graph)(pl, frames, B, H, W, im_scale, rois, cls, box);
 }
 
+// detection.py:145-148: int(round(coordinate / scale)) for the four coordinates of each row.
+__global__ __launch_bounds__(256) void boxes_to_source_kernel(const float* __restrict__ dets, int total, double scale,
+                                                             int32_t* __restrict__ out) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    out[i] = (int32_t)rint((double)dets[(size_t)(i >> 2) * 5 + (i & 3)] / scale);
+}
+
 }  // namespace fd
 
 // =================================================================================
@@ -693,6 +701,25 @@ int fd_detect(fd_detector* d, const uint8_t* frames, int batch, int height, int 
     FD_TRY(fd::forward(d, frames, batch, height, width, 1.0f, &r, &c, &b, s));
     FD_TRY(fd::postprocess_run(d->ctx, r, 5, c, b, batch, d->prop.post_nms_top_n, height, width, thresh, nms_thresh,
                                do_round, dets, n_dets, s));
+    if (nan_flag) FD_HIP(hipMemcpyAsync(nan_flag, d->nan_flag, sizeof(int32_t), hipMemcpyDeviceToDevice, s));
+    return FD_OK;
+}
+
+int fd_detect_scaled(fd_detector* d, const uint8_t* frames, int batch, int height, int width, float im_scale,
+                     float thresh, float nms_thresh, float* dets, int32_t* n_dets, int32_t* boxes_src,
+                     int32_t* nan_flag, void* stream) {
+    FD_REQUIRE(d && dets && n_dets && im_scale > 0.0f, "fd_detect_scaled: bad arguments");
+    float *r = nullptr, *c = nullptr, *b = nullptr;
+    hipStream_t s = fd::as_stream(stream);
+    FD_TRY(fd::forward(d, frames, batch, height, width, im_scale, &r, &c, &b, s));
+    FD_TRY(fd::postprocess_run(d->ctx, r, 5, c, b, batch, d->prop.post_nms_top_n, height, width, thresh, nms_thresh,
+                               0, dets, n_dets, s));
+    if (boxes_src) {
+        const int total = batch * d->prop.post_nms_top_n * 4;
+        hipLaunchKernelGGL(fd::boxes_to_source_kernel, dim3(fd::ceil_div(total, 256)), dim3(256), 0, s, dets, total,
+                           (double)im_scale, boxes_src);
+        FD_LAUNCH_CHECK();
+    }
     if (nan_flag) FD_HIP(hipMemcpyAsync(nan_flag, d->nan_flag, sizeof(int32_t), hipMemcpyDeviceToDevice, s));
     return FD_OK;
 }

@@ -40,17 +40,19 @@ __device__ __forceinline__ Tap2 linear_tap(int d, double scale, int ssize) {
 
 __global__ __launch_bounds__(256) void resize_linear_u8_kernel(const uint8_t* __restrict__ src, int sh, int sw, int c,
                                                               double scale_x, double scale_y, uint8_t* __restrict__ dst,
-                                                              int dh, int dw, int area2) {
+                                                              int dh, int dw, int area2, int reverse) {
     const int dx = blockIdx.x * 64 + (threadIdx.x & 63);
     const int dy = blockIdx.y * 4 + (threadIdx.x >> 6);
     const int b = blockIdx.z;
     if (dx >= dw || dy >= dh) return;
     const uint8_t* s = src + (size_t)b * sh * sw * c;
     uint8_t* o = dst + (((size_t)b * dh + dy) * dw + dx) * c;
+    // reverse: destination channel k takes source channel c-1-k (BGR <-> RGB)
+    const int o0 = reverse ? c - 1 : 0, os = reverse ? -1 : 1;
     if (area2) {
         const uint8_t* r0 = s + ((size_t)(2 * dy) * sw + 2 * dx) * c;
         const uint8_t* r1 = r0 + (size_t)sw * c;
-        for (int k = 0; k < c; ++k) o[k] = (uint8_t)((r0[k] + r0[c + k] + r1[k] + r1[c + k] + 2) >> 2);
+        for (int k = 0; k < c; ++k) o[o0 + os * k] = (uint8_t)((r0[k] + r0[c + k] + r1[k] + r1[c + k] + 2) >> 2);
         return;
     }
     const Tap2 tx = linear_tap(dx, scale_x, sw);
@@ -60,7 +62,7 @@ __global__ __launch_bounds__(256) void resize_linear_u8_kernel(const uint8_t* __
     for (int k = 0; k < c; ++k) {
         const int h0 = r0[tx.s0 * c + k] * tx.w0 + r0[tx.s1 * c + k] * tx.w1;
         const int h1 = r1[tx.s0 * c + k] * tx.w0 + r1[tx.s1 * c + k] * tx.w1;
-        o[k] = (uint8_t)((((ty.w0 * (h0 >> 4)) >> 16) + ((ty.w1 * (h1 >> 4)) >> 16) + 2) >> 2);
+        o[o0 + os * k] = (uint8_t)((((ty.w0 * (h0 >> 4)) >> 16) + ((ty.w1 * (h1 >> 4)) >> 16) + 2) >> 2);
     }
 }
 
@@ -160,6 +162,11 @@ int fd_resize_dims(int src_h, int src_w, double fx, double fy, int* dst_h, int* 
 
 int fd_resize_u8(fd_ctx* ctx, const uint8_t* src, int batch, int src_h, int src_w, int channels, double fx, double fy,
                  uint8_t* dst, int dst_h, int dst_w, void* stream) {
+    return fd_resize_cvt_u8(ctx, src, batch, src_h, src_w, channels, fx, fy, 0, dst, dst_h, dst_w, stream);
+}
+
+int fd_resize_cvt_u8(fd_ctx* ctx, const uint8_t* src, int batch, int src_h, int src_w, int channels, double fx,
+                     double fy, int reverse_channels, uint8_t* dst, int dst_h, int dst_w, void* stream) {
     (void)ctx;
     FD_REQUIRE(src && dst && batch > 0 && channels > 0 && channels <= 4, "fd_resize_u8: bad arguments");
     int eh = 0, ew = 0;
@@ -172,7 +179,7 @@ int fd_resize_u8(fd_ctx* ctx, const uint8_t* src, int batch, int src_h, int src_
                         (double)batch * channels * ((double)src_h * src_w + (double)dst_h * dst_w));
     dim3 grid(fd::ceil_div(dst_w, 64), fd::ceil_div(dst_h, 4), batch);
     hipLaunchKernelGGL(fd::resize_linear_u8_kernel, grid, dim3(256), 0, fd::as_stream(stream), src, src_h, src_w,
-                       channels, scale_x, scale_y, dst, dst_h, dst_w, area2);
+                       channels, scale_x, scale_y, dst, dst_h, dst_w, area2, reverse_channels ? 1 : 0);
     FD_LAUNCH_CHECK();
     return FD_OK;
 }

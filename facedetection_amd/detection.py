@@ -171,6 +171,40 @@ class Detector:
             dets_host = dets.cpu().numpy()
             return [dets_host[b, :n_host[b]].copy() for b in range(f.shape[0])]
 
+    def detect_scaled_batch(self, frames, target_size=600, max_size=1000, nms_thresh=0.3, thresh=0.8, bgr=True):
+        """The command-line loop of detection.py:105-148 for a same-size batch of decoded frames
+        (uint8 [B,H,W,3], BGR as a video decoder delivers them when ``bgr``): colour order
+        swapped to RGB, short side resized to ``target_size`` (long side capped at ``max_size``),
+        forward with im_info = (h, w, scale), tail without rounding, boxes mapped back with
+        int(round(x / scale)).  Returns (list of float32 [n_i,5] rows in resized-frame pixels,
+        list of int32 [n_i,4] boxes in source-frame pixels, scale)."""
+        with torch.cuda.device(self.device):
+            f = self._frames(frames)
+            B, H, W, _ = (int(v) for v in f.shape)
+            scale = float(target_size) / float(min(H, W))
+            if np.round(scale * max(H, W)) > max_size:
+                scale = float(max_size) / float(max(H, W))
+            dh, dw = C.c_int32(0), C.c_int32(0)
+            _lib.check(self._lib.fd_resize_dims(H, W, scale, scale, C.byref(dh), C.byref(dw)))
+            small = runtime.empty((B, dh.value, dw.value, 3), torch.uint8, self.device)
+            stream = runtime.stream_ptr(self.device)
+            _lib.check(self._lib.fd_resize_cvt_u8(self._rt.handle, runtime.ptr(f), B, H, W, 3, scale, scale,
+                                                  1 if bgr else 0, runtime.ptr(small), dh.value, dw.value, stream))
+            R = self.rois_per_image
+            dets = runtime.empty((B, R, 5), torch.float32, self.device)
+            n = runtime.empty((B,), torch.int32, self.device)
+            src = runtime.empty((B, R, 4), torch.int32, self.device)
+            flag = runtime.empty((1,), torch.int32, self.device)
+            _lib.check(self._lib.fd_detect_scaled(self._h, runtime.ptr(small), B, dh.value, dw.value, scale,
+                                                  float(thresh), float(nms_thresh), runtime.ptr(dets), runtime.ptr(n),
+                                                  runtime.ptr(src), runtime.ptr(flag), stream))
+            n_host = n.cpu().numpy()
+            if int(flag.item()) != 0:
+                raise ValueError("there is nan in input scores or bbox_deltas")
+            d_host, s_host = dets.cpu().numpy(), src.cpu().numpy()
+            return ([d_host[b, :n_host[b]].copy() for b in range(B)],
+                    [s_host[b, :n_host[b]].copy() for b in range(B)], scale)
+
     def detect_face(self, img_np, nms_thresh=0.3, thresh=0.8):
         """detection.py:33-60: one HWC uint8 frame -> float32 [N,5]."""
         return self.detect_batch(img_np, nms_thresh, thresh, True)[0]

@@ -141,6 +141,10 @@ int fd_postprocess(fd_ctx* ctx, const float* rois, const float* scores, const fl
 int fd_resize_dims(int src_h, int src_w, double fx, double fy, int* dst_h_host, int* dst_w_host);
 int fd_resize_u8(fd_ctx* ctx, const uint8_t* src, int batch, int src_h, int src_w, int channels, double fx,
                  double fy, uint8_t* dst, int dst_h, int dst_w, void* stream);
+/* The same with cv2.cvtColor(color, cv2.COLOR_BGR2RGB) (detection.py:109) folded in when
+ * reverse_channels != 0: destination channel k holds source channel channels-1-k. */
+int fd_resize_cvt_u8(fd_ctx* ctx, const uint8_t* src, int batch, int src_h, int src_w, int channels, double fx,
+                     double fy, int reverse_channels, uint8_t* dst, int dst_h, int dst_w, void* stream);
 
 /* Face crops ------------------------------------------------------------------------
  * Function.stick_boxes (code/common/Function.py:49-70) followed by Function.resize_pad
@@ -228,6 +232,16 @@ int fd_detect(fd_detector* det, const uint8_t* frames, int batch, int height, in
  * recycled inside a pass, so by default only conv0, feat and the tensors after it still hold
  * their values afterwards; fd_detector_keep_tensors(det, 1) makes later passes snapshot every
  * named tensor (allocating: debugging only). */
+/* The command-line loop's variant (detection.py:110-148): frames are already resized by
+ * im_scale (im_info = (height, width, im_scale), so the proposal stage's minimum size scales
+ * with it), the tail does not round, and each kept box is mapped back to the source frame as
+ * int(round(coordinate / im_scale)) -- boxes_src int32 [batch, rois_per_image, 4], may be
+ * NULL.  dets float32 [batch, rois_per_image, 5] holds the unrounded rows in resized-frame
+ * pixels.  Rounding is half-to-even on the float64 quotient. */
+int fd_detect_scaled(fd_detector* det, const uint8_t* frames, int batch, int height, int width, float im_scale,
+                     float thresh, float nms_thresh, float* dets, int32_t* n_dets, int32_t* boxes_src,
+                     int32_t* nan_flag, void* stream);
+
 int fd_detector_keep_tensors(fd_detector* det, int keep);
 int fd_detector_tensor(fd_detector* det, const char* name, float* out, int64_t capacity, int64_t* dims4,
                        void* stream);
