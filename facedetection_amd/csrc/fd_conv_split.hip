@@ -283,7 +283,9 @@ __global__ __launch_bounds__(256, 2) void conv_split_glds_kernel(SplitKArgs a, u
     constexpr int SMEM = (2 * STAGE > EPI) ? 2 * STAGE : EPI;
     __shared__ __attribute__((aligned(16))) float smem[SMEM];
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // the wave index is uniform: keeping it in a scalar register makes every LDS destination
+    // address of the loads below scalar arithmetic
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
     int wgid;
     {
@@ -318,35 +320,45 @@ __global__ __launch_bounds__(256, 2) void conv_split_glds_kernel(SplitKArgs a, u
         wi0[i] = wo * a.stride - a.pad;
         abase[i] = (unsigned)(((img * a.H + hi0[i]) * a.W + wi0[i]) * a.Cin * 4 + chunk * 16);
     }
-    unsigned bbase[GB];
+    unsigned bvo[GB];                            // weights: per-lane offset, constant over the K loop
 #pragma unroll
     for (int i = 0; i < GB; ++i) {
         const int row = (wave + 4 * i) * 8 + lrow;
         const int chunk = lpos ^ ((row >> 1) & 7);
-        bbase[i] = (unsigned)((tile_n * BN + row) * a.K * 4 + chunk * 16);
+        bvo[i] = (unsigned)((tile_n * BN + row) * a.K * 4 + chunk * 16);
     }
     int kh = 0, kw = 0, coff = 0;
     const int nk = a.K / SBK;
 
-#define FD_ISSUE(KT, STG)                                                                         \
+    // Per-lane offsets of the activation rows change only with the filter tap (validity of the
+    // tap for the row's window); the channel position inside the tap and the K position in the
+    // weights are uniform and travel in the instruction's scalar offset.
+    unsigned avo[GA];
+#define FD_TAP()                                                                                  \
     do {                                                                                          \
-        const unsigned toff_ = (unsigned)(((kh * a.W + kw) * a.Cin + coff) * 4);                  \
-        float* sa_ = smem + (STG) * STAGE;                                                        \
+        const unsigned toff_ = (unsigned)((kh * a.W + kw) * a.Cin * 4);                           \
         _Pragma("unroll") for (int i = 0; i < GA; ++i) {                                          \
             const int hi_ = hi0[i] + kh, wi_ = wi0[i] + kw;                                       \
             const bool ok_ = mval[i] && (unsigned)hi_ < (unsigned)a.H && (unsigned)wi_ < (unsigned)a.W; \
-            const unsigned vo_ = ok_ ? abase[i] + toff_ : OOB;                                    \
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(                                             \
-                xr, (__attribute__((address_space(3))) void*)(sa_ + (wave + 4 * i) * 256), 16, vo_, 0, 0, 0); \
+            avo[i] = ok_ ? abase[i] + toff_ : OOB;                                                \
         }                                                                                         \
+    } while (0)
+
+#define FD_ISSUE(KT, STG)                                                                         \
+    do {                                                                                          \
+        float* sa_ = smem + (STG) * STAGE;                                                        \
+        _Pragma("unroll") for (int i = 0; i < GA; ++i)                                            \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(                                             \
+                xr, (__attribute__((address_space(3))) void*)(sa_ + (wave + 4 * i) * 256), 16, avo[i], coff * 4, 0, 0); \
         _Pragma("unroll") for (int i = 0; i < GB; ++i)                                            \
             __builtin_amdgcn_raw_ptr_buffer_load_lds(                                             \
                 wr, (__attribute__((address_space(3))) void*)(sa_ + BM * 32 + (wave + 4 * i) * 256), 16, \
-                bbase[i] + (unsigned)(KT) * 128u, 0, 0, 0);                                       \
+                bvo[i], (KT) * 128, 0, 0);                                                        \
         coff += SBK;                                                                              \
         if (coff >= a.Cin) {                                                                      \
             coff = 0;                                                                             \
             if (++kw == a.KW) { kw = 0; ++kh; }                                                   \
+            FD_TAP();                                                                             \
         }                                                                                         \
     } while (0)
 
@@ -359,45 +371,55 @@ __global__ __launch_bounds__(256, 2) void conv_split_glds_kernel(SplitKArgs a, u
             for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
 
     // fragment addressing: row R (R & 31 == lane & 31 for every tile of this wave), chunk
-    // (part * 4 + kg * 2 + half) stored at position chunk ^ ((R >> 1) & 7)
+    // (part * 4 + kg * 2 + half) stored at position chunk ^ ((R >> 1) & 7).  The four byte
+    // offsets (k-group x hi/lo) per operand are fixed; stage and tile index are immediates.
     const int frow = lane & 31, fh = lane >> 5;
     const int sw = (frow >> 1) & 7;
-    const int a_row = (wm * (BM / 2) + frow) * 32;
-    const int b_row = (BM + wn * (BN / 2) + frow) * 32;
+    const char* sbase = reinterpret_cast<const char*>(smem);
+    int a_off[2][2], b_off[2][2];
+#pragma unroll
+    for (int kg = 0; kg < 2; ++kg)
+#pragma unroll
+        for (int part = 0; part < 2; ++part) {
+            const int pos = ((part * 4 + kg * 2 + fh) ^ sw) * 16;
+            a_off[kg][part] = (wm * (BM / 2) + frow) * 128 + pos;
+            b_off[kg][part] = (BM + wn * (BN / 2) + frow) * 128 + pos;
+        }
 
+#define FD_STEP(CUR, KT)                                                                          \
+    do {                                                                                          \
+        if ((KT) + 1 < nk) FD_ISSUE((KT) + 1, (CUR) ^ 1);                                         \
+        _Pragma("unroll") for (int kg = 0; kg < 2; ++kg) {                                        \
+            f16x8 ah[MT], al[MT], bh[NT], bl[NT];                                                 \
+            _Pragma("unroll") for (int mi = 0; mi < MT; ++mi) {                                   \
+                ah[mi] = *reinterpret_cast<const f16x8*>(sbase + a_off[kg][0] + (CUR) * STAGE * 4 + mi * 4096); \
+                al[mi] = *reinterpret_cast<const f16x8*>(sbase + a_off[kg][1] + (CUR) * STAGE * 4 + mi * 4096); \
+            }                                                                                     \
+            _Pragma("unroll") for (int ni = 0; ni < NT; ++ni) {                                   \
+                bh[ni] = *reinterpret_cast<const f16x8*>(sbase + b_off[kg][0] + (CUR) * STAGE * 4 + ni * 4096); \
+                bl[ni] = *reinterpret_cast<const f16x8*>(sbase + b_off[kg][1] + (CUR) * STAGE * 4 + ni * 4096); \
+            }                                                                                     \
+            _Pragma("unroll") for (int mi = 0; mi < MT; ++mi)                                     \
+                _Pragma("unroll") for (int ni = 0; ni < NT; ++ni) {                               \
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[mi], bh[ni], acc[mi][ni], 0, 0, 0); \
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mi], bl[ni], acc[mi][ni], 0, 0, 0); \
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mi], bh[ni], acc[mi][ni], 0, 0, 0); \
+                }                                                                                 \
+        }                                                                                         \
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                          \
+        __syncthreads();                                                                          \
+    } while (0)
+
+    FD_TAP();
     FD_ISSUE(0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    for (int kt = 0; kt < nk; ++kt) {
-        const int cur = kt & 1;
-        if (kt + 1 < nk) FD_ISSUE(kt + 1, cur ^ 1);
-        const float* st = smem + cur * STAGE;
-#pragma unroll
-        for (int kg = 0; kg < 2; ++kg) {
-            const int ph = ((kg * 2 + fh) ^ sw) * 4, pl = ((4 + kg * 2 + fh) ^ sw) * 4;
-            f16x8 ah[MT], al[MT], bh[NT], bl[NT];
-#pragma unroll
-            for (int mi = 0; mi < MT; ++mi) {
-                ah[mi] = *reinterpret_cast<const f16x8*>(st + a_row + mi * 32 * 32 + ph);
-                al[mi] = *reinterpret_cast<const f16x8*>(st + a_row + mi * 32 * 32 + pl);
-            }
-#pragma unroll
-            for (int ni = 0; ni < NT; ++ni) {
-                bh[ni] = *reinterpret_cast<const f16x8*>(st + b_row + ni * 32 * 32 + ph);
-                bl[ni] = *reinterpret_cast<const f16x8*>(st + b_row + ni * 32 * 32 + pl);
-            }
-#pragma unroll
-            for (int mi = 0; mi < MT; ++mi)
-#pragma unroll
-                for (int ni = 0; ni < NT; ++ni) {
-                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[mi], bh[ni], acc[mi][ni], 0, 0, 0);
-                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mi], bl[ni], acc[mi][ni], 0, 0, 0);
-                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mi], bh[ni], acc[mi][ni], 0, 0, 0);
-                }
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
+    for (int kt = 0; kt < nk; kt += 2) {
+        FD_STEP(0, kt);
+        if (kt + 1 < nk) FD_STEP(1, kt + 1);
     }
+#undef FD_STEP
+#undef FD_TAP
 #undef FD_ISSUE
 
     // epilogue (same as the register-staged kernel; the staging slice lives at the start of smem)
