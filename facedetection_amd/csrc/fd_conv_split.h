@@ -26,6 +26,12 @@ int pack_conv_weights_split(const float* w_oihw, int cin_w, const ConvShape& s, 
 int split_conv_forward(const SplitConvParams& p, const void* x_split, int batch, int h, int w, const float* residual,
                        const SplitConvOut& out, hipStream_t stream);
 
+// The same convolution on a float32 input [B][H][W][cin] that enters as
+// split(relu(x * pre_scale[c] + pre_shift[c])), converted while the tile is staged.
+int split_conv_forward_f32(const SplitConvParams& p, const float* x32, const float* pre_scale, const float* pre_shift,
+                           int batch, int h, int w, const float* residual, const SplitConvOut& out,
+                           hipStream_t stream);
+
 // float32 [rows][channels] -> split, optionally through relu(x * scale[c] + shift[c]).
 int to_split(const float* x, long long rows, int channels, const float* scale, const float* shift, void* y,
              hipStream_t stream);

@@ -26,6 +26,8 @@ struct SplitKArgs {
     uint8_t* ysplit;         // split output or NULL
     const float* post_scale; // BatchNorm+ReLU applied to the split output only (NULL: raw)
     const float* post_shift;
+    const float* pre_scale;  // PRE kernels: x is float32 and enters as split(relu(x * pre_scale[c] + pre_shift[c]))
+    const float* pre_shift;
     float w_inv_scale;
     int H, W, Cin, Ho, Wo, Cout, KW, stride, pad, K, M, relu, tiles_n;
 };
@@ -33,7 +35,10 @@ struct SplitKArgs {
 constexpr int SBK = 32;      // k per K-step
 constexpr int SLDK = 36;     // staged row: 128 B of data + 16 B pad, in dwords
 
-template <int BM, int BN, bool STEM>
+// PRE: the input tensor is float32 (same 4 bytes per element, so the same addressing) and the
+// consumer's BatchNorm+ReLU and the fp16 split happen between the global load and the LDS
+// store.  This lets the producer write the float32 tensor only instead of both forms.
+template <int BM, int BN, bool STEM, bool PRE = false>
 __global__ __launch_bounds__(256, 2) void conv_split_kernel(SplitKArgs a) {
     constexpr int RA = BM / 32, RB = BN / 32;
     constexpr int MT = BM / 64, NT = BN / 64;
@@ -77,12 +82,17 @@ __global__ __launch_bounds__(256, 2) void conv_split_kernel(SplitKArgs a) {
     for (int i = 0; i < RB; ++i) wrow[i] = wf + (size_t)(tile_n * BN + r0 + 32 * i) * a.K + c4 * 4;
 
     f32x4 ra[RA], rb[RB];
+    f32x4 psc = {1.f, 1.f, 1.f, 1.f}, psh = {0.f, 0.f, 0.f, 0.f};
     unsigned okbits = 0;
     int kh = 0, kw = 0, coff = 0;
     const int nk = a.K / SBK;
 
 #define FD_GLOAD(KT)                                                                              \
     do {                                                                                          \
+        if (PRE) {                                                                                \
+            psc = *reinterpret_cast<const f32x4*>(a.pre_scale + coff + c4 * 4);                   \
+            psh = *reinterpret_cast<const f32x4*>(a.pre_shift + coff + c4 * 4);                   \
+        }                                                                                         \
         const int th_ = STEM ? (KT) : kh;                                                         \
         const int tw_ = STEM ? c4 : kw;                                                           \
         const int toff_ = STEM ? (KT) * a.W * 4 : (kh * a.W + kw) * a.Cin + coff;                 \
@@ -111,8 +121,21 @@ __global__ __launch_bounds__(256, 2) void conv_split_kernel(SplitKArgs a) {
     do {                                                                                          \
         _Pragma("unroll") for (int i = 0; i < RA; ++i) {                                          \
             f32x4 v_ = ra[i];                                                                     \
-            if (!((okbits >> i) & 1u)) v_ = f32x4{0.f, 0.f, 0.f, 0.f};                            \
             float* row_ = &As[BUF][(r0 + 32 * i) * SLDK];                                         \
+            if (PRE) {                                                                            \
+                f16x4 h_, l_;                                                                     \
+                _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                   \
+                    float t_ = fmaxf(v_[j] * psc[j] + psh[j], 0.f);                               \
+                    if (!((okbits >> i) & 1u)) t_ = 0.f;                                          \
+                    _Float16 hh_, ll_;                                                            \
+                    split_f32(t_, hh_, ll_);                                                      \
+                    h_[j] = hh_; l_[j] = ll_;                                                     \
+                }                                                                                 \
+                *reinterpret_cast<f16x4*>(row_ + c4 * 2) = h_;                                    \
+                *reinterpret_cast<f16x4*>(row_ + 16 + c4 * 2) = l_;                               \
+                continue;                                                                         \
+            }                                                                                     \
+            if (!((okbits >> i) & 1u)) v_ = f32x4{0.f, 0.f, 0.f, 0.f};                            \
             if (STEM) {                                                                           \
                 *reinterpret_cast<float2*>(row_ + c4 * 2) = make_float2(v_[0], v_[1]);            \
                 *reinterpret_cast<float2*>(row_ + 16 + c4 * 2) = make_float2(v_[2], v_[3]);       \
@@ -519,10 +542,10 @@ static int launch_split_glds(const SplitKArgs& a, size_t x_bytes, size_t w_bytes
     return FD_OK;
 }
 
-template <int BM, int BN, bool STEM>
+template <int BM, int BN, bool STEM, bool PRE = false>
 static int launch_split(const SplitKArgs& a, hipStream_t stream) {
-    static const std::string name =
-        std::string("conv_split_") + std::to_string(BM) + "x" + std::to_string(BN) + (STEM ? "_stem" : "");
+    static const std::string name = std::string("conv_split_") + std::to_string(BM) + "x" + std::to_string(BN) +
+                                    (STEM ? "_stem" : "") + (PRE ? "_pre" : "");
     const double taps = STEM ? 147.0 : (double)a.K;
     const double cin_bytes = STEM ? 16.0 : 4.0 * a.Cin;
     ProfScope scope(stream, name.c_str(), 2.0 * a.M * a.Cout * taps,
@@ -531,13 +554,14 @@ static int launch_split(const SplitKArgs& a, hipStream_t stream) {
     SplitKArgs k = a;
     const int tiles_m = ceil_div(a.M, BM);
     k.tiles_n = ceil_div(a.Cout, BN);
-    hipLaunchKernelGGL((conv_split_kernel<BM, BN, STEM>), dim3(tiles_m * k.tiles_n), dim3(256), 0, stream, k);
+    hipLaunchKernelGGL((conv_split_kernel<BM, BN, STEM, PRE>), dim3(tiles_m * k.tiles_n), dim3(256), 0, stream, k);
     FD_LAUNCH_CHECK();
     return FD_OK;
 }
 
-int split_conv_forward(const SplitConvParams& p, const void* x_split, int batch, int h, int w, const float* residual,
-                       const SplitConvOut& out, hipStream_t stream) {
+static int split_conv_dispatch(const SplitConvParams& p, const void* x_split, const float* pre_scale,
+                               const float* pre_shift, int batch, int h, int w, const float* residual,
+                               const SplitConvOut& out, hipStream_t stream) {
     const ConvShape& s = p.s;
     FD_REQUIRE(x_split && p.w && (out.y32 || out.ysplit), "split conv: NULL tensor");
     FD_REQUIRE(batch > 0 && h > 0 && w > 0, "split conv: bad input shape %d x %d x %d", batch, h, w);
@@ -555,13 +579,20 @@ int split_conv_forward(const SplitConvParams& p, const void* x_split, int batch,
     a.w = static_cast<const uint8_t*>(p.w);
     a.bias = p.bias; a.res = residual; a.y32 = out.y32; a.ysplit = static_cast<uint8_t*>(out.ysplit);
     a.post_scale = out.post_scale; a.post_shift = out.post_shift; a.w_inv_scale = p.w_inv_scale;
+    a.pre_scale = pre_scale; a.pre_shift = pre_shift;
     a.H = h; a.W = w; a.Cin = s.cin; a.Ho = ho; a.Wo = wo; a.Cout = s.cout; a.KW = s.kwp;
     a.stride = s.stride; a.pad = s.pad; a.K = s.k(); a.M = (int)m_ll; a.relu = p.relu; a.tiles_n = 0;
+    FD_REQUIRE(!(stem && pre_scale), "split conv: the stem takes the staged image only");
     if (stem) return launch_split<128, 64, true>(a, stream);
     const long long t128 = (long long)ceil_div(a.M, 128) * ceil_div(s.cout, 128);
     const long long t12864 = (long long)ceil_div(a.M, 128) * ceil_div(s.cout, 64);
     // the direct-to-LDS kernels address both tensors with 32-bit byte offsets below 2^31
     const size_t x_bytes = (size_t)batch * h * w * s.cin * 4, w_bytes = s.packed_floats() * 4;
+    if (pre_scale) {
+        if (s.cout > 64 && t128 >= 384) return launch_split<128, 128, false, true>(a, stream);
+        if (t12864 >= 384) return launch_split<128, 64, false, true>(a, stream);
+        return launch_split<64, 64, false, true>(a, stream);
+    }
     const bool glds = x_bytes < (1ull << 31) && w_bytes < (1ull << 31);
     if (glds) {
         if (s.cout > 64 && t128 >= 384) return launch_split_glds<128, 128>(a, x_bytes, w_bytes, stream);
@@ -571,6 +602,18 @@ int split_conv_forward(const SplitConvParams& p, const void* x_split, int batch,
     if (s.cout > 64 && t128 >= 384) return launch_split<128, 128, false>(a, stream);
     if (t12864 >= 384) return launch_split<128, 64, false>(a, stream);
     return launch_split<64, 64, false>(a, stream);
+}
+
+int split_conv_forward(const SplitConvParams& p, const void* x_split, int batch, int h, int w, const float* residual,
+                       const SplitConvOut& out, hipStream_t stream) {
+    return split_conv_dispatch(p, x_split, nullptr, nullptr, batch, h, w, residual, out, stream);
+}
+
+int split_conv_forward_f32(const SplitConvParams& p, const float* x32, const float* pre_scale, const float* pre_shift,
+                           int batch, int h, int w, const float* residual, const SplitConvOut& out,
+                           hipStream_t stream) {
+    FD_REQUIRE(pre_scale && pre_shift, "split conv: the float32-input form needs the BatchNorm scale and shift");
+    return split_conv_dispatch(p, x32, pre_scale, pre_shift, batch, h, w, residual, out, stream);
 }
 
 // ---------------------------------------------------------------------------------
@@ -775,10 +818,13 @@ int fd_conv2d_f16x3(fd_ctx* ctx, const float* x_nhwc, int batch, int height, int
     FD_TRY(fd::scratch(ctx, fd::SLOT_MISC0, p.s.packed_floats() * sizeof(float), &packed));
     FD_TRY(fd::scratch(ctx, fd::SLOT_MISC1, (size_t)batch * height * width * cin * sizeof(float), &xs));
     FD_TRY(fd::pack_conv_weights_split(w_oihw, cin, p.s, nullptr, wscale, packed, st));
-    FD_TRY(fd::to_split(x_nhwc, (long long)batch * height * width, cin, pre_scale, pre_shift, xs, st));
     p.w = packed; p.w_inv_scale = 1.0f / wscale; p.bias = bias; p.relu = relu;
     fd::SplitConvOut o;
     o.y32 = y_nhwc;
+    // with a BatchNorm+ReLU prologue the kernel converts float32 input while staging it
+    if (pre_scale && pre_shift)
+        return fd::split_conv_forward_f32(p, x_nhwc, pre_scale, pre_shift, batch, height, width, residual, o, st);
+    FD_TRY(fd::to_split(x_nhwc, (long long)batch * height * width, cin, nullptr, nullptr, xs, st));
     return fd::split_conv_forward(p, xs, batch, height, width, residual, o, st);
 }
 

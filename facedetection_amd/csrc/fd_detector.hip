@@ -415,8 +415,9 @@ static int run_graph(Plan& pl, const uint8_t* frames, int B, int H, int W, float
 
 // ----------------------------------------------------------------------------- split-precision graph
 // Same layer sequence with every convolution on the f16 matrix cores (fd_conv_split.hip).
-// A unit consumes act = split(relu(bn1(x))) -- written by whoever produced x -- and, when its
-// shortcut is the identity, the raw float32 x.
+// A projection-shortcut unit consumes act = split(relu(bn1(x))), written by whoever produced
+// x.  An identity-shortcut unit gets the raw float32 x only: its first convolution applies
+// bn1+relu and splits while loading, so the producer writes x once instead of in both forms.
 static int run_unit_split(Plan& pl, const Unit& u, const char* name, const void* act, const float* xraw, int n, int h,
                           int w, float* y32, void* ysplit, const float* next_scale, const float* next_shift,
                           int* ho_out, int* wo_out) {
@@ -442,7 +443,12 @@ static int run_unit_split(Plan& pl, const Unit& u, const char* name, const void*
         o3.ysplit = ysplit;
         o3.post_scale = next_scale;
         o3.post_shift = next_shift;
-        FD_TRY(split_conv_forward(u.s_conv1, act, n, h, w, nullptr, o1, pl.stream));
+        if (u.has_sc) {
+            FD_TRY(split_conv_forward(u.s_conv1, act, n, h, w, nullptr, o1, pl.stream));
+        } else {
+            FD_TRY(split_conv_forward_f32(u.s_conv1, xraw, u.bn1_scale, u.bn1_shift, n, h, w, nullptr, o1,
+                                          pl.stream));
+        }
         FD_TRY(split_conv_forward(u.s_conv2, t1, n, h, w, nullptr, o2, pl.stream));
         FD_TRY(split_conv_forward(u.s_conv3, t2, n, ho, wo, res, o3, pl.stream));
     }
@@ -495,8 +501,10 @@ static int run_graph_split(Plan& pl, const uint8_t* frames, int B, int H, int W,
             // the raw sum is needed by an identity-shortcut successor, by ROI pooling, or for inspection
             const bool want32 = last || keep || (next && !next->has_sc);
             float* y32 = want32 ? xbuf[cur ^ 1] : nullptr;
+            // the split form is for a projection-shortcut successor and, after the last unit, the RPN
+            const bool want_split = last || (next && next->has_sc);
             FD_TRY(run_unit_split(pl, d->stage[s][u], name, abuf[cur], d->stage[s][u].has_sc ? nullptr : xraw, B, h, w,
-                                  y32, abuf[cur ^ 1], next ? next->bn1_scale : nullptr,
+                                  y32, want_split ? abuf[cur ^ 1] : nullptr, next ? next->bn1_scale : nullptr,
                                   next ? next->bn1_shift : nullptr, &h, &w));
             xraw = y32;
             cur ^= 1;
@@ -553,7 +561,8 @@ static int run_graph_split(Plan& pl, const uint8_t* frames, int B, int H, int W,
         const bool last = u + 1 == d->stage[3].size();
         const Unit* next = last ? nullptr : &d->stage[3][u + 1];
         FD_TRY(run_unit_split(pl, d->stage[3][u], name, a4buf[cur], d->stage[3][u].has_sc ? nullptr : xraw, N, h, w,
-                              x4buf[cur ^ 1], last ? nullptr : a4buf[cur ^ 1], next ? next->bn1_scale : nullptr,
+                              x4buf[cur ^ 1], (next && next->has_sc) ? a4buf[cur ^ 1] : nullptr,
+                              next ? next->bn1_scale : nullptr,
                               next ? next->bn1_shift : nullptr, &h, &w));
         xraw = x4buf[cur ^ 1];
         cur ^= 1;
