@@ -12,6 +12,8 @@
 
 #include <cfloat>
 #include <cmath>
+#include <cstdlib>
+#include <type_traits>
 #include <string>
 #include <vector>
 
@@ -294,7 +296,7 @@ __global__ __launch_bounds__(256, 2) void conv_split_kernel(SplitKArgs a) {
 // padded; instead the 16-byte chunk c of row r is stored at chunk position c ^ ((r >> 1) & 7),
 // which makes the fragment reads (16 lanes, 16 distinct rows, same chunk) conflict-free.  The
 // permutation is applied on the global source address of each lane and undone when reading.
-template <int BM, int BN>
+template <int BM, int BN, bool S16>
 __global__ __launch_bounds__(256, 2) void conv_split_glds_kernel(SplitKArgs a, unsigned x_bytes, unsigned w_bytes) {
 #if defined(__HIP_DEVICE_COMPILE__)   // buffer-resource builtins exist in device code only; the host pass needs just the stub
     constexpr int GA = BM / 32, GB = BN / 32;   // 8-row groups per wave per K-step
@@ -385,18 +387,23 @@ __global__ __launch_bounds__(256, 2) void conv_split_glds_kernel(SplitKArgs a, u
         }                                                                                         \
     } while (0)
 
-    f32x16 acc[MT][NT];
+    // S16: 16x16x32 blocks (one fragment read covers the whole K-step), else 32x32x16 blocks
+    constexpr int AM = S16 ? MT * 2 : MT, AN = S16 ? NT * 2 : NT;
+    typedef typename std::conditional<S16, f32x4, f32x16>::type acc_t;
+    constexpr int AR = S16 ? 4 : 16;
+    acc_t acc[AM][AN];
 #pragma unroll
-    for (int mi = 0; mi < MT; ++mi)
+    for (int mi = 0; mi < AM; ++mi)
 #pragma unroll
-        for (int ni = 0; ni < NT; ++ni)
+        for (int ni = 0; ni < AN; ++ni)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+            for (int r = 0; r < AR; ++r) acc[mi][ni][r] = 0.f;
 
-    // fragment addressing: row R (R & 31 == lane & 31 for every tile of this wave), chunk
-    // (part * 4 + kg * 2 + half) stored at position chunk ^ ((R >> 1) & 7).  The four byte
-    // offsets (k-group x hi/lo) per operand are fixed; stage and tile index are immediates.
-    const int frow = lane & 31, fh = lane >> 5;
+    // fragment addressing: row R, chunk c (hi chunks 0..3, lo chunks 4..7 of the 128-byte row)
+    // stored at position c ^ ((R >> 1) & 7).  32x32x16: R & 31 == lane & 31, c = part * 4 +
+    // kg * 2 + (lane >> 5).  16x16x32: R & 15 == lane & 15, c = part * 4 + (lane >> 4).  Either
+    // way the byte offsets per operand are fixed; stage and block index are immediates.
+    const int frow = S16 ? (lane & 15) : (lane & 31), fh = S16 ? (lane >> 4) : (lane >> 5);
     const int sw = (frow >> 1) & 7;
     const char* sbase = reinterpret_cast<const char*>(smem);
     int a_off[2][2], b_off[2][2];
@@ -404,7 +411,7 @@ __global__ __launch_bounds__(256, 2) void conv_split_glds_kernel(SplitKArgs a, u
     for (int kg = 0; kg < 2; ++kg)
 #pragma unroll
         for (int part = 0; part < 2; ++part) {
-            const int pos = ((part * 4 + kg * 2 + fh) ^ sw) * 16;
+            const int pos = ((S16 ? part * 4 + fh : part * 4 + kg * 2 + fh) ^ sw) * 16;
             a_off[kg][part] = (wm * (BM / 2) + frow) * 128 + pos;
             b_off[kg][part] = (BM + wn * (BN / 2) + frow) * 128 + pos;
         }
@@ -412,6 +419,23 @@ __global__ __launch_bounds__(256, 2) void conv_split_glds_kernel(SplitKArgs a, u
 #define FD_STEP(CUR, KT)                                                                          \
     do {                                                                                          \
         if ((KT) + 1 < nk) FD_ISSUE((KT) + 1, (CUR) ^ 1);                                         \
+        if constexpr (S16) {                                                                      \
+            f16x8 ah[AM], al[AM], bh[AN], bl[AN];                                                 \
+            _Pragma("unroll") for (int mi = 0; mi < AM; ++mi) {                                   \
+                ah[mi] = *reinterpret_cast<const f16x8*>(sbase + a_off[0][0] + (CUR) * STAGE * 4 + mi * 2048); \
+                al[mi] = *reinterpret_cast<const f16x8*>(sbase + a_off[0][1] + (CUR) * STAGE * 4 + mi * 2048); \
+            }                                                                                     \
+            _Pragma("unroll") for (int ni = 0; ni < AN; ++ni) {                                   \
+                bh[ni] = *reinterpret_cast<const f16x8*>(sbase + b_off[0][0] + (CUR) * STAGE * 4 + ni * 2048); \
+                bl[ni] = *reinterpret_cast<const f16x8*>(sbase + b_off[0][1] + (CUR) * STAGE * 4 + ni * 2048); \
+            }                                                                                     \
+            _Pragma("unroll") for (int mi = 0; mi < AM; ++mi)                                     \
+                _Pragma("unroll") for (int ni = 0; ni < AN; ++ni) {                               \
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[mi], bh[ni], acc[mi][ni], 0, 0, 0); \
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[mi], bl[ni], acc[mi][ni], 0, 0, 0); \
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[mi], bh[ni], acc[mi][ni], 0, 0, 0); \
+                }                                                                                 \
+        } else                                                                                    \
         _Pragma("unroll") for (int kg = 0; kg < 2; ++kg) {                                        \
             f16x8 ah[MT], al[MT], bh[NT], bl[NT];                                                 \
             _Pragma("unroll") for (int mi = 0; mi < MT; ++mi) {                                   \
@@ -453,10 +477,11 @@ __global__ __launch_bounds__(256, 2) void conv_split_glds_kernel(SplitKArgs a, u
     const int erow = lane / L8, ecol = (lane % L8) * 8;
     const int gcol = tile_n * BN + wn * WN + ecol;
     const bool col_ok = gcol < a.Cout;
-    float bias_v[NT];
+    constexpr int CB = S16 ? 16 : 32;         // columns per accumulator block
+    float bias_v[AN];
 #pragma unroll
-    for (int ni = 0; ni < NT; ++ni) {
-        const int col = tile_n * BN + wn * WN + ni * 32 + (lane & 31);
+    for (int ni = 0; ni < AN; ++ni) {
+        const int col = tile_n * BN + wn * WN + ni * CB + (lane & (CB - 1));
         bias_v[ni] = (a.bias && col < a.Cout) ? a.bias[col] : 0.f;
     }
     f32x4 ps0 = {1.f, 1.f, 1.f, 1.f}, ps1 = ps0, pt0 = {0.f, 0.f, 0.f, 0.f}, pt1 = pt0;
@@ -485,14 +510,28 @@ __global__ __launch_bounds__(256, 2) void conv_split_glds_kernel(SplitKArgs a, u
             }
         }
         __syncthreads();
+        if constexpr (S16) {
+            // 16x16 block: column = lane & 15, row = (lane >> 4) * 4 + register
 #pragma unroll
-        for (int ni = 0; ni < NT; ++ni)
+            for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                float v = acc[mi][ni][r] * a.w_inv_scale + bias_v[ni];
-                if (a.relu) v = fmaxf(v, 0.f);
-                Cs[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * LDC + ni * 32 + (lane & 31)] = v;
-            }
+                for (int ni = 0; ni < AN; ++ni)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float v = acc[mi * 2 + mb][ni][r] * a.w_inv_scale + bias_v[ni];
+                        if (a.relu) v = fmaxf(v, 0.f);
+                        Cs[(mb * 16 + (lane >> 4) * 4 + r) * LDC + ni * 16 + (lane & 15)] = v;
+                    }
+        } else {
+#pragma unroll
+            for (int ni = 0; ni < AN; ++ni)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    float v = acc[mi][ni][r] * a.w_inv_scale + bias_v[ni];
+                    if (a.relu) v = fmaxf(v, 0.f);
+                    Cs[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * LDC + ni * 32 + (lane & 31)] = v;
+                }
+        }
         __syncthreads();
 #pragma unroll
         for (int ps = 0; ps < PASSES; ++ps) {
@@ -527,6 +566,19 @@ __global__ __launch_bounds__(256, 2) void conv_split_glds_kernel(SplitKArgs a, u
 #endif
 }
 
+// Block shape of the direct-to-LDS kernels: v_mfma_f32_16x16x32_f16 unless FD_MFMA_SHAPE=32 is
+// set in the environment (read once).  Both shapes issue the same cycles per FLOP and read the
+// same LDS bytes, but under sustained load the chip holds a higher clock on the 16x16x32 form:
+// measured +4.6 % frames/s on the whole 1080p pipeline.  The switch exists to repeat that
+// comparison.
+static bool use_shape16() {
+    static const bool v = [] {
+        const char* e = getenv("FD_MFMA_SHAPE");
+        return !(e && atoi(e) == 32);
+    }();
+    return v;
+}
+
 template <int BM, int BN>
 static int launch_split_glds(const SplitKArgs& a, size_t x_bytes, size_t w_bytes, hipStream_t stream) {
     static const std::string name = std::string("conv_split_") + std::to_string(BM) + "x" + std::to_string(BN);
@@ -536,8 +588,12 @@ static int launch_split_glds(const SplitKArgs& a, size_t x_bytes, size_t w_bytes
     SplitKArgs k = a;
     const int tiles_m = ceil_div(a.M, BM);
     k.tiles_n = ceil_div(a.Cout, BN);
-    hipLaunchKernelGGL((conv_split_glds_kernel<BM, BN>), dim3(tiles_m * k.tiles_n), dim3(256), 0, stream, k,
-                       (unsigned)x_bytes, (unsigned)w_bytes);
+    if (use_shape16())
+        hipLaunchKernelGGL((conv_split_glds_kernel<BM, BN, true>), dim3(tiles_m * k.tiles_n), dim3(256), 0, stream, k,
+                           (unsigned)x_bytes, (unsigned)w_bytes);
+    else
+        hipLaunchKernelGGL((conv_split_glds_kernel<BM, BN, false>), dim3(tiles_m * k.tiles_n), dim3(256), 0, stream,
+                           k, (unsigned)x_bytes, (unsigned)w_bytes);
     FD_LAUNCH_CHECK();
     return FD_OK;
 }
