@@ -55,11 +55,12 @@ def pmc_traffic(kernel):
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic.json")))
     if not m or not files or kernel.endswith("_stem"):
         return None, None
-    want = "<%s, %s>" % (m.group(2), m.group(3))
+    want = "<%s, %s" % (m.group(2), m.group(3))
     with open(files[-1]) as f:
         table = json.load(f)["kernels"]
+    pre = kernel.endswith("_pre")
     for name, row in table.items():
-        if want in name and ("split_glds" in name) == (m.group(1) == "split"):
+        if want in name and ("split_glds" in name) == (m.group(1) == "split" and not pre):
             return row["hbm_bytes_per_launch"], os.path.basename(files[-1])
     return None, None
 
@@ -91,6 +92,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--frames", type=int, default=256, help="frames per step per GPU")
     ap.add_argument("--batch", type=int, default=8, help="frames per launch sequence")
+    ap.add_argument("--streams", type=int, default=2,
+                    help="HIP streams the micro-batches are spread over (each with its own detector)")
     ap.add_argument("--precision", default="f16x3", choices=["f16x3", "f32"],
                     help="convolution arithmetic: exact two-way fp16 operand split (default) or float32 operands")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -113,18 +116,15 @@ def main():
     device = torch.device("cuda", local)
 
     from facedetection_amd import profiling
-    from facedetection_amd.detection import Detector
     from facedetection_amd.parallel import gather_detections
+    from facedetection_amd.pipeline import FramePipeline
 
-    det = Detector("synthetic:0", local, precision=args.precision)
+    pipe = FramePipeline("synthetic:0", local, streams=args.streams, precision=args.precision)
     frames = make_frames(args.frames, device, seed=rank)
     B = max(1, min(args.batch, args.frames))
 
     def step():
-        outs = []
-        for i in range(0, args.frames, B):
-            outs.append(det.detect_batch_device(frames[i:i + B]))
-        return outs
+        return pipe.detect_device(frames, B)
 
     def barrier():
         if distributed:
@@ -142,6 +142,16 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     rows = [] if args.no_profile else profiling.end()
+    # With more than one stream a launch shares the GPU with the other stream's kernels, so its
+    # event-bracketed duration is longer than on an idle chip.  One extra, untimed step on a single
+    # stream gives the isolated per-kernel durations next to the ones of the timed region.
+    iso_rows = []
+    if rows and args.streams > 1:
+        profiling.begin()
+        for i in range(0, args.frames, B):
+            pipe.detectors[0].detect_batch_device(frames[i:i + B])
+        torch.cuda.synchronize()
+        iso_rows = profiling.end()
 
     if distributed:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
@@ -171,8 +181,10 @@ def main():
             "dtype": "f32" if args.precision == "f32" else "f32 (operands as exact fp16 hi+lo pairs, 3 f16 MFMAs per product, f32 accumulate)",
             "data": "synthetic",
             "config": {"workload": "batch of %d synthetic 1080p frames per GPU resident in HBM, full Faster R-CNN "
-                                   "(ResNet-50) cascade, micro-batches of %d" % (args.frames, B),
-                       "frames_per_step_per_gpu": args.frames, "micro_batch": B, "height": H, "width": W,
+                                   "(ResNet-50) cascade, micro-batches of %d round-robin over %d HIP stream(s)"
+                                   % (args.frames, B, args.streams),
+                       "frames_per_step_per_gpu": args.frames, "micro_batch": B, "streams": args.streams,
+                       "height": H, "width": W,
                        "rpn_pre_nms_top_n": 1000, "rpn_post_nms_top_n": 10, "rpn_min_size": 50,
                        "weights": "seeded random (synthetic:0)", "detections_in_last_step": n_boxes},
         }
@@ -196,6 +208,15 @@ def main():
                 "all_conv_tflops": round(sum(r["flops"] for r in conv) / (sum(r["ms"] for r in conv) * 1e-3) / 1e12, 3),
                 "pipeline_tflops": round(GFLOP_PER_FRAME * fps / 1e3, 3),
             }
+            if iso_rows:
+                iso = [r for r in iso_rows if r["kernel"] == dom["kernel"]][0]
+                itf = iso["flops"] / (iso["ms"] * 1e-3) / 1e12
+                line["roofline"]["isolated"] = {
+                    "achieved": round(itf, 3), "frac": round(itf / peak, 4),
+                    "avg_launch_ms": round(iso["ms"] / iso["launches"], 4),
+                    "note": "same kernel in one extra untimed step on a single stream; in the timed region "
+                            "its launches overlap the other stream's kernels, which lengthens each launch "
+                            "while raising whole-pipeline throughput"}
             line["kernels"] = [
                 {"kernel": r["kernel"], "launches": r["launches"], "ms": round(r["ms"], 3),
                  "tflops": round(r["flops"] / (r["ms"] * 1e-3) / 1e12, 3) if r["flops"] else None,

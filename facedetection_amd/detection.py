@@ -51,7 +51,10 @@ def load_model(model_path, epoch=0):
 class Detector:
     """Faster R-CNN face detector (ResNet-50 backbone) on one MI355X."""
 
-    def __init__(self, model_path, ctx=None, epoch=0, box_f64=True, precision="f16x3"):
+    def __init__(self, model_path, ctx=None, epoch=0, box_f64=True, precision="f16x3", own_context=False):
+        """``own_context``: give this detector a library context (scratch memory) of its own
+        instead of the per-GPU shared one, so that it can run concurrently with other
+        detectors of the process on a different HIP stream."""
         config.TEST.RPN_MIN_SIZE = 50            # detection.py:27
         self.device = _device_of(ctx)
         self.ctx = ctx
@@ -59,7 +62,8 @@ class Detector:
         params = load_model(model_path, epoch)
         self._lib = _lib.lib()
         with torch.cuda.device(self.device):
-            self._rt = runtime.context(self.device)
+            self._rt = runtime.Context(self.device) if own_context else runtime.context(self.device)
+            self._own_rt = own_context
             # the parameter arrays must stay alive and contiguous during the call only
             keep = []
             arr = (_lib.Param * len(params))()
@@ -99,6 +103,8 @@ class Detector:
         if getattr(self, "_h", None):
             self._lib.fd_detector_destroy(self._h)
             self._h = None
+            if getattr(self, "_own_rt", False):
+                self._rt.close()
 
     def __del__(self):
         try:

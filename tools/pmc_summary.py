@@ -36,7 +36,7 @@ def main():
         out[short] = {"launches": n, "fetch_bytes_per_launch": round(fetch), "write_bytes_per_launch": round(write),
                       "hbm_bytes_per_launch": round(fetch + write)}
     json.dump({"note": "FETCH_SIZE x2 (gfx950 wide-read correction) + WRITE_SIZE, KiB -> bytes, averaged per launch; "
-                       "command: bench.py --frames 16 --steps 1 --warmup 1 (micro-batch 8, 1080p)",
+                       "command: bench.py --frames 16 --steps 1 --warmup 1 --streams 1 (micro-batch 8, 1080p)",
                "kernels": out}, open(sys.argv[3], "w"), indent=1, sort_keys=True)
     for k, v in sorted(out.items(), key=lambda kv: -kv[1]["hbm_bytes_per_launch"] * kv[1]["launches"])[:8]:
         print("%-50s %4d launches  %8.1f MB/launch" % (k[:50], v["launches"], v["hbm_bytes_per_launch"] / 1e6))
