@@ -566,6 +566,331 @@ __global__ __launch_bounds__(256, 2) void conv_split_glds_kernel(SplitKArgs a, u
 #endif
 }
 
+// ---------------------------------------------------------------------------------
+// Register-staged activations on the same LDS image as the direct-to-LDS kernel (swizzled
+// 128-byte rows, 16x16x32 blocks, weights by LDS-DMA).  Two uses:
+//   REG_PRE  - the input is float32; BatchNorm+ReLU and the fp16 split happen between the
+//              global load and the LDS store (first convolution of identity-shortcut units);
+//   REG_STEM - the 7x7/2 stem on the staged 4-channel image: a K-step is one kernel row,
+//              k = 4 * kw + c, a thread's 16 bytes are one pixel [4 hi | 4 lo].
+// In both a thread's 16 global bytes become 8 bytes of the hi half of a row (chunk c4 >> 1,
+// byte (c4 & 1) * 8) and 8 bytes of the lo half (chunk 4 + (c4 >> 1)).  Loads are buffer
+// loads: per-lane offsets change with the filter tap only, the channel offset is scalar, and
+// padding taps read zeros through the range check.
+enum { REG_PRE = 0, REG_STEM = 1 };
+
+template <int BM, int BN>
+struct SplitTile {
+    static constexpr int STAGE = (BM + BN) * 32;      // dwords per pipeline stage
+    static constexpr int WN = BN / 2;
+    static constexpr int LDC = WN + 4;
+    static constexpr int EPI = 4 * 32 * LDC;          // epilogue staging, dwords
+    static constexpr int SMEM = (2 * STAGE > EPI) ? 2 * STAGE : EPI;
+    static constexpr int AM = BM / 32, AN = BN / 32;  // 16x16 blocks per wave
+};
+
+// all MFMAs of one K-step (32 k) of a wave's tile from the stage at `stage`
+template <int BM, int BN>
+__device__ __forceinline__ void split_mma_step(const char* stage, const int (&a_off)[2], const int (&b_off)[2],
+                                               f32x4 (&acc)[BM / 32][BN / 32]) {
+    constexpr int AM = BM / 32, AN = BN / 32;
+    f16x8 ah[AM], al[AM], bh[AN], bl[AN];
+#pragma unroll
+    for (int mi = 0; mi < AM; ++mi) {
+        ah[mi] = *reinterpret_cast<const f16x8*>(stage + a_off[0] + mi * 2048);
+        al[mi] = *reinterpret_cast<const f16x8*>(stage + a_off[1] + mi * 2048);
+    }
+#pragma unroll
+    for (int ni = 0; ni < AN; ++ni) {
+        bh[ni] = *reinterpret_cast<const f16x8*>(stage + b_off[0] + ni * 2048);
+        bl[ni] = *reinterpret_cast<const f16x8*>(stage + b_off[1] + ni * 2048);
+    }
+#pragma unroll
+    for (int mi = 0; mi < AM; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < AN; ++ni) {
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[mi], bh[ni], acc[mi][ni], 0, 0, 0);
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[mi], bl[ni], acc[mi][ni], 0, 0, 0);
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[mi], bh[ni], acc[mi][ni], 0, 0, 0);
+        }
+}
+
+// Epilogue of a 16x16-block tile: transpose each wave's rows through its slice of LDS (32 rows
+// at a time); every lane then owns 8 consecutive channels of a row.
+template <int BM, int BN>
+__device__ __forceinline__ void split_epilogue16(const SplitKArgs& a, float* smem, int tile_m, int tile_n, int wave,
+                                                 int lane, f32x4 (&acc)[BM / 32][BN / 32]) {
+    using T = SplitTile<BM, BN>;
+    constexpr int WN = T::WN, LDC = T::LDC, AN = T::AN;
+    constexpr int L8 = WN / 8;
+    constexpr int RPP = 64 / L8;
+    constexpr int PASSES = 32 / RPP;
+    const int wm = wave >> 1, wn = wave & 1;
+    float* Cs = smem + wave * (32 * LDC);
+    const int erow = lane / L8, ecol = (lane % L8) * 8;
+    const int gcol = tile_n * BN + wn * WN + ecol;
+    const bool col_ok = gcol < a.Cout;
+    float bias_v[AN];
+#pragma unroll
+    for (int ni = 0; ni < AN; ++ni) {
+        const int col = tile_n * BN + wn * WN + ni * 16 + (lane & 15);
+        bias_v[ni] = (a.bias && col < a.Cout) ? a.bias[col] : 0.f;
+    }
+    f32x4 ps0 = {1.f, 1.f, 1.f, 1.f}, ps1 = ps0, pt0 = {0.f, 0.f, 0.f, 0.f}, pt1 = pt0;
+    const bool post = a.ysplit && a.post_scale && col_ok;
+    if (post) {
+        ps0 = *reinterpret_cast<const f32x4*>(a.post_scale + gcol);
+        ps1 = *reinterpret_cast<const f32x4*>(a.post_scale + gcol + 4);
+        pt0 = *reinterpret_cast<const f32x4*>(a.post_shift + gcol);
+        pt1 = *reinterpret_cast<const f32x4*>(a.post_shift + gcol + 4);
+    }
+#pragma unroll
+    for (int mi = 0; mi < BM / 64; ++mi) {
+        const int grow0 = tile_m * BM + wm * (BM / 2) + mi * 32;
+        f32x4 res0[PASSES], res1[PASSES];
+        if (a.res) {
+#pragma unroll
+            for (int ps = 0; ps < PASSES; ++ps) {
+                const int row = grow0 + ps * RPP + erow;
+                res0[ps] = f32x4{0.f, 0.f, 0.f, 0.f};
+                res1[ps] = res0[ps];
+                if (row < a.M && col_ok) {
+                    const float* rp = a.res + (size_t)row * a.Cout + gcol;
+                    res0[ps] = *reinterpret_cast<const f32x4*>(rp);
+                    res1[ps] = *reinterpret_cast<const f32x4*>(rp + 4);
+                }
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+            for (int ni = 0; ni < AN; ++ni)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float v = acc[mi * 2 + mb][ni][r] * a.w_inv_scale + bias_v[ni];
+                    if (a.relu) v = fmaxf(v, 0.f);
+                    Cs[(mb * 16 + (lane >> 4) * 4 + r) * LDC + ni * 16 + (lane & 15)] = v;
+                }
+        __syncthreads();
+#pragma unroll
+        for (int ps = 0; ps < PASSES; ++ps) {
+            const int lrow2 = ps * RPP + erow;
+            const int row = grow0 + lrow2;
+            f32x4 v0 = *reinterpret_cast<const f32x4*>(&Cs[lrow2 * LDC + ecol]);
+            f32x4 v1 = *reinterpret_cast<const f32x4*>(&Cs[lrow2 * LDC + ecol + 4]);
+            if (a.res) { v0 += res0[ps]; v1 += res1[ps]; }
+            if (row < a.M && col_ok) {
+                if (a.y32) {
+                    float* yp = a.y32 + (size_t)row * a.Cout + gcol;
+                    *reinterpret_cast<f32x4*>(yp) = v0;
+                    *reinterpret_cast<f32x4*>(yp + 4) = v1;
+                }
+                if (a.ysplit) {
+                    if (post) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            v0[j] = fmaxf(v0[j] * ps0[j] + pt0[j], 0.f);
+                            v1[j] = fmaxf(v1[j] * ps1[j] + pt1[j], 0.f);
+                        }
+                    }
+                    f16x8 hi, lo;
+                    split8(v0, v1, hi, lo);
+                    uint8_t* sp = a.ysplit + (size_t)row * a.Cout * 4 + split_offset(gcol);
+                    *reinterpret_cast<f16x8*>(sp) = hi;
+                    *reinterpret_cast<f16x8*>(sp + 64) = lo;
+                }
+            }
+        }
+    }
+}
+
+template <int BM, int BN, int MODE>
+__global__ __launch_bounds__(256, 2) void conv_split_reg_kernel(SplitKArgs a, unsigned x_bytes, unsigned w_bytes) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    using T = SplitTile<BM, BN>;
+    constexpr int RA = BM / 32;                  // activation rows per thread and K-step
+    constexpr int GB = BN / 32;                  // weight 8-row groups per wave and K-step
+    constexpr int STAGE = T::STAGE;
+    __shared__ __attribute__((aligned(16))) float smem[T::SMEM];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    int wgid;
+    {
+        const int nwg = gridDim.x, bid = blockIdx.x;
+        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+        wgid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    }
+    const int tile_n = wgid % a.tiles_n, tile_m = wgid / a.tiles_n;
+
+    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, w_bytes, 0x00020000);
+    constexpr unsigned OOB = 0x80000000u;
+
+    // activations: thread -> rows r0 + 32 i, global 16-byte chunk c4 of the K-step
+    const int c4 = tid & 7, r0 = tid >> 3;
+    int hi0[RA], wi0[RA];
+    unsigned abase[RA], a_lds[RA];
+    bool mval[RA];
+#pragma unroll
+    for (int i = 0; i < RA; ++i) {
+        const int row = r0 + 32 * i;
+        const int m = tile_m * BM + row;
+        mval[i] = m < a.M;
+        const int mm = mval[i] ? m : 0;
+        const int hw = a.Ho * a.Wo;
+        const int img = mm / hw;
+        const int rem = mm - img * hw;
+        const int ho = rem / a.Wo;
+        const int wo = rem - ho * a.Wo;
+        hi0[i] = ho * a.stride - a.pad;
+        wi0[i] = wo * a.stride - a.pad;
+        abase[i] = (unsigned)(((img * a.H + hi0[i]) * a.W + wi0[i]) * a.Cin * 4 + c4 * 16);
+        a_lds[i] = (unsigned)(row * 128 + (((c4 >> 1) ^ ((row >> 1) & 7)) * 16) + (c4 & 1) * 8);
+    }
+    // weights: as in the direct-to-LDS kernel
+    const int lrow = lane >> 3, lpos = lane & 7;
+    unsigned bvo[GB];
+#pragma unroll
+    for (int i = 0; i < GB; ++i) {
+        const int row = (wave + 4 * i) * 8 + lrow;
+        const int chunk = lpos ^ ((row >> 1) & 7);
+        bvo[i] = (unsigned)((tile_n * BN + row) * a.K * 4 + chunk * 16);
+    }
+    int kh = 0, kw = 0, coff = 0;
+    const int nk = a.K / SBK;
+    unsigned avo[RA], okbits = 0;
+    f32x4 ra[RA];
+    f32x4 psc = {1.f, 1.f, 1.f, 1.f}, psh = {0.f, 0.f, 0.f, 0.f};
+
+#define FD_TAP()                                                                                  \
+    do {                                                                                          \
+        const unsigned toff_ = (unsigned)((kh * a.W + kw) * a.Cin * 4);                           \
+        okbits = 0;                                                                               \
+        _Pragma("unroll") for (int i = 0; i < RA; ++i) {                                          \
+            const int hi_ = hi0[i] + kh, wi_ = wi0[i] + (MODE == REG_STEM ? c4 : kw);             \
+            const bool ok_ = mval[i] && (unsigned)hi_ < (unsigned)a.H && (unsigned)wi_ < (unsigned)a.W; \
+            avo[i] = ok_ ? abase[i] + toff_ : OOB;                                                \
+            okbits |= ok_ ? (1u << i) : 0u;                                                       \
+        }                                                                                         \
+    } while (0)
+
+    // global loads of K-step KT: activations into registers, weights straight into stage STG
+#define FD_GLOAD(KT, STG)                                                                         \
+    do {                                                                                          \
+        _Pragma("unroll") for (int i = 0; i < RA; ++i)                                            \
+            ra[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xr, avo[i], coff * 4, 0)); \
+        if (MODE == REG_PRE) {                                                                    \
+            psc = *reinterpret_cast<const f32x4*>(a.pre_scale + coff + c4 * 4);                   \
+            psh = *reinterpret_cast<const f32x4*>(a.pre_shift + coff + c4 * 4);                   \
+        }                                                                                         \
+        lok = okbits;                                                                             \
+        float* sa_ = smem + (STG) * STAGE;                                                        \
+        _Pragma("unroll") for (int i = 0; i < GB; ++i)                                            \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(                                             \
+                wr, (__attribute__((address_space(3))) void*)(sa_ + BM * 32 + (wave + 4 * i) * 256), 16, \
+                bvo[i], (KT) * 128, 0, 0);                                                        \
+        if (MODE == REG_STEM) {                                                                   \
+            ++kh;                                                                                 \
+            FD_TAP();                                                                             \
+        } else {                                                                                  \
+            coff += SBK;                                                                          \
+            if (coff >= a.Cin) {                                                                  \
+                coff = 0;                                                                         \
+                if (++kw == a.KW) { kw = 0; ++kh; }                                               \
+                FD_TAP();                                                                         \
+            }                                                                                     \
+        }                                                                                         \
+    } while (0)
+
+    // registers -> LDS stage STG: BatchNorm+ReLU+split (PRE) or the staged halves as they are (STEM)
+#define FD_LSTORE(STG)                                                                            \
+    do {                                                                                          \
+        char* sb_ = reinterpret_cast<char*>(smem) + (STG) * STAGE * 4;                            \
+        _Pragma("unroll") for (int i = 0; i < RA; ++i) {                                          \
+            f16x4 h_, l_;                                                                         \
+            if (MODE == REG_PRE) {                                                                \
+                _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                   \
+                    float t_ = fmaxf(ra[i][j] * psc[j] + psh[j], 0.f);                            \
+                    if (!((lok >> i) & 1u)) t_ = 0.f;                                             \
+                    _Float16 hh_, ll_;                                                            \
+                    split_f32(t_, hh_, ll_);                                                      \
+                    h_[j] = hh_; l_[j] = ll_;                                                     \
+                }                                                                                 \
+            } else {                                                                              \
+                const float2 p0_ = make_float2(ra[i][0], ra[i][1]), p1_ = make_float2(ra[i][2], ra[i][3]); \
+                h_ = __builtin_bit_cast(f16x4, p0_);                                              \
+                l_ = __builtin_bit_cast(f16x4, p1_);                                              \
+            }                                                                                     \
+            *reinterpret_cast<f16x4*>(sb_ + a_lds[i]) = h_;                                       \
+            *reinterpret_cast<f16x4*>(sb_ + (a_lds[i] ^ 64u)) = l_;                               \
+        }                                                                                         \
+    } while (0)
+
+    f32x4 acc[T::AM][T::AN];
+#pragma unroll
+    for (int mi = 0; mi < T::AM; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < T::AN; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int frow = lane & 15, fh = lane >> 4;
+    const int sw = (frow >> 1) & 7;
+    const char* sbase = reinterpret_cast<const char*>(smem);
+    int a_off[2], b_off[2];
+#pragma unroll
+    for (int part = 0; part < 2; ++part) {
+        const int pos = ((part * 4 + fh) ^ sw) * 16;
+        a_off[part] = (wm * (BM / 2) + frow) * 128 + pos;
+        b_off[part] = (BM + wn * (BN / 2) + frow) * 128 + pos;
+    }
+    unsigned lok = 0;     // validity bits that belong to the registers in flight
+
+#define FD_STEP(CUR, KT)                                                                          \
+    do {                                                                                          \
+        const bool more_ = (KT) + 1 < nk;                                                         \
+        if (more_) FD_GLOAD((KT) + 1, (CUR) ^ 1);                                                 \
+        split_mma_step<BM, BN>(sbase + (CUR) * STAGE * 4, a_off, b_off, acc);                     \
+        if (more_) FD_LSTORE((CUR) ^ 1);                                                          \
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                          \
+        __syncthreads();                                                                          \
+    } while (0)
+
+    FD_TAP();
+    FD_GLOAD(0, 0);
+    FD_LSTORE(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int kt = 0; kt < nk; kt += 2) {
+        FD_STEP(0, kt);
+        if (kt + 1 < nk) FD_STEP(1, kt + 1);
+    }
+#undef FD_STEP
+#undef FD_LSTORE
+#undef FD_GLOAD
+#undef FD_TAP
+    split_epilogue16<BM, BN>(a, smem, tile_m, tile_n, wave, lane, acc);
+#endif
+}
+
+template <int BM, int BN, int MODE>
+static int launch_split_reg(const SplitKArgs& a, size_t x_bytes, size_t w_bytes, hipStream_t stream) {
+    static const std::string name = std::string("conv_split_") + std::to_string(BM) + "x" + std::to_string(BN) +
+                                    (MODE == REG_STEM ? "_stem" : "_pre");
+    const double taps = MODE == REG_STEM ? 147.0 : (double)a.K;
+    const double cin_bytes = MODE == REG_STEM ? 16.0 : 4.0 * a.Cin;
+    ProfScope scope(stream, name.c_str(), 2.0 * a.M * a.Cout * taps,
+                    (double)a.H * a.W * (a.M / ((double)a.Ho * a.Wo)) * cin_bytes + 4.0 * a.Cout * taps +
+                        4.0 * a.M * a.Cout * ((a.res ? 1.0 : 0.0) + (a.y32 ? 1.0 : 0.0) + (a.ysplit ? 1.0 : 0.0)));
+    SplitKArgs k = a;
+    const int tiles_m = ceil_div(a.M, BM);
+    k.tiles_n = ceil_div(a.Cout, BN);
+    hipLaunchKernelGGL((conv_split_reg_kernel<BM, BN, MODE>), dim3(tiles_m * k.tiles_n), dim3(256), 0, stream, k,
+                       (unsigned)x_bytes, (unsigned)w_bytes);
+    FD_LAUNCH_CHECK();
+    return FD_OK;
+}
+
 // Block shape of the direct-to-LDS kernels: v_mfma_f32_16x16x32_f16 unless FD_MFMA_SHAPE=32 is
 // set in the environment (read once).  Both shapes issue the same cycles per FLOP and read the
 // same LDS bytes, but under sustained load the chip holds a higher clock on the 16x16x32 form:
@@ -639,18 +964,26 @@ static int split_conv_dispatch(const SplitConvParams& p, const void* x_split, co
     a.H = h; a.W = w; a.Cin = s.cin; a.Ho = ho; a.Wo = wo; a.Cout = s.cout; a.KW = s.kwp;
     a.stride = s.stride; a.pad = s.pad; a.K = s.k(); a.M = (int)m_ll; a.relu = p.relu; a.tiles_n = 0;
     FD_REQUIRE(!(stem && pre_scale), "split conv: the stem takes the staged image only");
-    if (stem) return launch_split<128, 64, true>(a, stream);
+    // the buffer-addressed kernels use 32-bit byte offsets below 2^31 into both tensors
+    const size_t x_bytes = (size_t)batch * h * w * s.cin * 4, w_bytes = s.packed_floats() * 4;
+    const bool small = x_bytes < (1ull << 31) && w_bytes < (1ull << 31);
+    if (stem) {
+        if (small && s.cout <= 64) return launch_split_reg<128, 64, REG_STEM>(a, x_bytes, w_bytes, stream);
+        return launch_split<128, 64, true>(a, stream);
+    }
     const long long t128 = (long long)ceil_div(a.M, 128) * ceil_div(s.cout, 128);
     const long long t12864 = (long long)ceil_div(a.M, 128) * ceil_div(s.cout, 64);
-    // the direct-to-LDS kernels address both tensors with 32-bit byte offsets below 2^31
-    const size_t x_bytes = (size_t)batch * h * w * s.cin * 4, w_bytes = s.packed_floats() * 4;
     if (pre_scale) {
+        if (small) {
+            if (s.cout > 64 && t128 >= 384) return launch_split_reg<128, 128, REG_PRE>(a, x_bytes, w_bytes, stream);
+            if (t12864 >= 384) return launch_split_reg<128, 64, REG_PRE>(a, x_bytes, w_bytes, stream);
+            return launch_split_reg<64, 64, REG_PRE>(a, x_bytes, w_bytes, stream);
+        }
         if (s.cout > 64 && t128 >= 384) return launch_split<128, 128, false, true>(a, stream);
         if (t12864 >= 384) return launch_split<128, 64, false, true>(a, stream);
         return launch_split<64, 64, false, true>(a, stream);
     }
-    const bool glds = x_bytes < (1ull << 31) && w_bytes < (1ull << 31);
-    if (glds) {
+    if (small) {
         if (s.cout > 64 && t128 >= 384) return launch_split_glds<128, 128>(a, x_bytes, w_bytes, stream);
         if (t12864 >= 384) return launch_split_glds<128, 64>(a, x_bytes, w_bytes, stream);
         return launch_split_glds<64, 64>(a, x_bytes, w_bytes, stream);
