@@ -234,40 +234,72 @@ __device__ __forceinline__ uint64_t wave_uniform_u64(uint64_t v) {
     return ((uint64_t)hi << 32) | lo;
 }
 
-// One workgroup per image walks the panel's candidates in chunks of 64.  Wave 0 resolves a
-// chunk against its own diagonal mask words; then every thread ORs the rows of the kept
-// boxes into its share of the `removed` bitmap (LDS; saved to / restored from removed_g
-// between panels).
+// Serial part, one workgroup per image and panel.  Chunk c (64 candidates) of the panel can be
+// resolved once it is known which earlier boxes are kept:
+//   rem_c = removed_g[c]                                   (kept boxes of earlier panels)
+//         | OR over kept rows r of this panel before chunk c of mask[r][c]
+//         | the chunk's own diagonal word, resolved bit by bit by one wave (v_readlane).
+// The middle term is pulled: every thread owns up to four panel rows and loads their word of
+// column c+1 while wave 0 is still resolving chunk c -- the loads do not depend on the result,
+// only the masking with the kept bits does -- so no global load sits on the serial chain.
+// Kept bits per chunk go to keptbits[] for the spread kernel; the running count stays in
+// counters[CNT_KEEP].
 constexpr int REDUCE_THREADS = 1024;
+constexpr int NMS_PANEL_ROWS = NMS_PANEL_CHUNKS * 64;
+constexpr int ROWS_PER_THREAD = NMS_PANEL_ROWS / REDUCE_THREADS;
 __global__ __launch_bounds__(REDUCE_THREADS) void nms_reduce_kernel(const uint64_t* __restrict__ mask,
                                                                    int32_t* __restrict__ counters,
-                                                                   uint64_t* __restrict__ removed_g, int cap, int words,
+                                                                   const uint64_t* __restrict__ removed_g,
+                                                                   uint64_t* __restrict__ keptbits, int cap, int words,
                                                                    int chunk0, int panel_rows, int max_keep,
                                                                    int32_t* __restrict__ keep) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    uint64_t* removed = reinterpret_cast<uint64_t*>(smem_raw);          // [words]
-    uint64_t* s_kept = removed + words;                                  // [1]
-    int* s_count = reinterpret_cast<int*>(s_kept + 1);                   // [1]
+    __shared__ uint64_t s_kept[NMS_PANEL_CHUNKS];
+    __shared__ unsigned long long s_rem;
+    __shared__ int s_count;
     const int seg = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+    uint64_t* segkb = keptbits + (size_t)seg * words;
     const int count0 = counters[seg * CNT_STRIDE + CNT_KEEP];
-    if (max_keep > 0 && count0 >= max_keep) return;
     const int n = counters[seg * CNT_STRIDE + CNT_CAND];
     const int W = (n + 63) >> 6;
-    if (chunk0 >= W) return;
     const int cend = min(chunk0 + panel_rows / 64, W);
+    // chunks this launch does not reach keep no box
+    for (int c = chunk0 + tid; c < chunk0 + panel_rows / 64 && c < words; c += REDUCE_THREADS) segkb[c] = 0ull;
+    if ((max_keep > 0 && count0 >= max_keep) || chunk0 >= W) return;
     const uint64_t* segm = mask + (size_t)seg * panel_rows * words;
-    uint64_t* segr = removed_g + (size_t)seg * words;
+    const uint64_t* segr = removed_g + (size_t)seg * words;
     int32_t* segk = keep + (size_t)seg * cap;
-    for (int w = chunk0 + tid; w < W; w += REDUCE_THREADS) removed[w] = (chunk0 == 0) ? 0ull : segr[w];
-    if (tid == 0) { *s_count = count0; *s_kept = 0; }
+    if (tid < NMS_PANEL_CHUNKS) s_kept[tid] = 0ull;
+    if (tid == 0) { s_count = count0; s_rem = 0ull; }
+    uint64_t pv[ROWS_PER_THREAD];
+#pragma unroll
+    for (int j = 0; j < ROWS_PER_THREAD; ++j) pv[j] = 0ull;
     __syncthreads();
     for (int c = chunk0; c < cend; ++c) {
-        const int lrow0 = (c - chunk0) * 64;        // first row of the chunk inside the panel
+        const int lrow0 = (c - chunk0) * 64;        // first panel row of the chunk
+        // pull: pv[] holds column c of this thread's rows (loaded during the previous chunk)
+        {
+            uint64_t acc = 0ull;
+#pragma unroll
+            for (int j = 0; j < ROWS_PER_THREAD; ++j) {
+                const int r = tid + j * REDUCE_THREADS;
+                if (r < lrow0 && ((s_kept[r >> 6] >> (r & 63)) & 1ull)) acc |= pv[j];
+            }
+            if (acc) atomicOr(&s_rem, (unsigned long long)acc);
+        }
+        __syncthreads();
+        // prefetch column c + 1 for every row up to and including this chunk's
+        if (c + 1 < cend) {
+#pragma unroll
+            for (int j = 0; j < ROWS_PER_THREAD; ++j) {
+                const int r = tid + j * REDUCE_THREADS;
+                pv[j] = (r < lrow0 + 64) ? segm[(size_t)r * words + c + 1] : 0ull;
+            }
+        }
         if (tid < 64) {
             const int i = c * 64 + lane;
             const uint64_t diag = (i < n) ? segm[(size_t)(lrow0 + lane) * words + c] : 0ull;
             const uint32_t dlo = (uint32_t)diag, dhi = (uint32_t)(diag >> 32);
-            uint64_t rem = wave_uniform_u64(removed[c]);
+            uint64_t rem = wave_uniform_u64((uint64_t)s_rem | (chunk0 == 0 ? 0ull : segr[c]));
             const int left = n - c * 64;
             if (left < 64) rem |= ~0ull << left;
             uint64_t kept = 0;
@@ -280,43 +312,63 @@ __global__ __launch_bounds__(REDUCE_THREADS) void nms_reduce_kernel(const uint64
                     rem |= ((uint64_t)hi << 32) | lo;
                 }
             }
-            const int count = *s_count;
+            const int count = s_count;
             if ((kept >> lane) & 1ull) {
                 const uint64_t below = (lane == 0) ? 0ull : (kept & (~0ull >> (64 - lane)));
                 const int pos = count + __popcll(below);
                 if (max_keep <= 0 || pos < max_keep) segk[pos] = i;
             }
             if (lane == 0) {
-                *s_kept = kept;
-                *s_count = count + __popcll(kept);
+                s_kept[c - chunk0] = kept;
+                segkb[c] = kept;
+                s_count = count + __popcll(kept);
+                s_rem = 0ull;
             }
         }
         __syncthreads();
-        const uint64_t kept = *s_kept;
-        const int count = *s_count;
-        if (max_keep > 0 && count >= max_keep) break;
-        for (int w = c + 1 + tid; w < W; w += REDUCE_THREADS) {
-            uint64_t acc = removed[w];
-            uint64_t k = kept;
-            while (k) {
-                const int b = __ffsll((long long)k) - 1;
-                k &= k - 1;
-                acc |= segm[(size_t)(lrow0 + b) * words + w];
-            }
-            removed[w] = acc;
-        }
-        __syncthreads();
+        if (max_keep > 0 && s_count >= max_keep) break;
     }
-    for (int w = cend + tid; w < W; w += REDUCE_THREADS) segr[w] = removed[w];
     if (tid == 0) {
-        int count = *s_count;
+        int count = s_count;
         if (max_keep > 0 && count > max_keep) count = max_keep;
         counters[seg * CNT_STRIDE + CNT_KEEP] = count;
     }
 }
 
-// The `removed` bitmap of one image lives in LDS during the reduce: cap / 8 bytes.
-constexpr long long NMS_MAX_CAND = 480000;
+// After a panel: OR the mask rows of its kept boxes into removed_g for all later columns.
+// grid (column blocks of 256 words, groups of 4 chunks of the panel, images).
+constexpr int SPREAD_CHUNKS = 4;
+__global__ __launch_bounds__(256) void nms_spread_kernel(const uint64_t* __restrict__ mask,
+                                                        const int32_t* __restrict__ counters,
+                                                        const uint64_t* __restrict__ keptbits,
+                                                        uint64_t* __restrict__ removed_g, int words, int chunk0,
+                                                        int panel_rows, int max_keep) {
+    const int seg = blockIdx.z;
+    if (max_keep > 0 && counters[seg * CNT_STRIDE + CNT_KEEP] >= max_keep) return;
+    const int n = counters[seg * CNT_STRIDE + CNT_CAND];
+    const int W = (n + 63) >> 6;
+    const int cend = chunk0 + panel_rows / 64;
+    const int w = cend + blockIdx.x * 256 + threadIdx.x;
+    const int cfirst = chunk0 + blockIdx.y * SPREAD_CHUNKS;
+    if (cfirst >= W) return;
+    const uint64_t* segm = mask + (size_t)seg * panel_rows * words;
+    const uint64_t* segkb = keptbits + (size_t)seg * words;
+    uint64_t acc = 0ull;
+    for (int c = cfirst; c < cfirst + SPREAD_CHUNKS && c < cend; ++c) {
+        uint64_t k = wave_uniform_u64(segkb[c]);
+        const uint64_t* rows = segm + (size_t)(c - chunk0) * 64 * words;
+        while (k) {
+            const int b = __ffsll((long long)k) - 1;
+            k &= k - 1;
+            if (w < W) acc |= rows[(size_t)b * words + w];
+        }
+    }
+    if (w < W && acc) atomicOr(reinterpret_cast<unsigned long long*>(removed_g + (size_t)seg * words + w),
+                               (unsigned long long)acc);
+}
+
+// Limited by the size of one mask panel (4096 x cap / 8 bytes) and by 32-bit indexing.
+constexpr long long NMS_MAX_CAND = 1 << 20;
 
 template <typename T>
 int nms_sorted(fd_ctx* ctx, const T* cand_boxes, int32_t* counters, int cap, int nseg, T thresh, int max_keep,
@@ -329,10 +381,13 @@ int nms_sorted(fd_ctx* ctx, const T* cand_boxes, int32_t* counters, int cap, int
     const int words = ceil_div(cap, 64);
     const int panel_chunks = words < NMS_PANEL_CHUNKS ? words : NMS_PANEL_CHUNKS;
     const int panel_rows = panel_chunks * 64;
-    uint64_t *mask = nullptr, *removed_g = nullptr;
+    uint64_t *mask = nullptr, *bits = nullptr;
     FD_TRY(scratch_as(ctx, SLOT_NMS_MASK, (size_t)nseg * panel_rows * words, &mask));
-    FD_TRY(scratch_as(ctx, SLOT_MISC2, (size_t)nseg * words, &removed_g));
-    const size_t smem = (size_t)words * 8 + 16;
+    FD_TRY(scratch_as(ctx, SLOT_MISC2, (size_t)nseg * words * 2, &bits));     // removed_g | keptbits
+    uint64_t* removed_g = bits;
+    uint64_t* keptbits = bits + (size_t)nseg * words;
+    const bool multi = words > panel_chunks;
+    if (multi) FD_HIP(hipMemsetAsync(removed_g, 0, (size_t)nseg * words * sizeof(uint64_t), stream));
     for (int chunk0 = 0; chunk0 < words; chunk0 += panel_chunks) {
         const int rows_here = (words - chunk0 < panel_chunks ? words - chunk0 : panel_chunks);
         {
@@ -345,15 +400,23 @@ int nms_sorted(fd_ctx* ctx, const T* cand_boxes, int32_t* counters, int cap, int
             FD_LAUNCH_CHECK();
         }
         {
-            ProfScope scope(stream, "nms_reduce", 0.0,
-                            (double)nseg * rows_here * 64.0 * (double)(words - chunk0) * 8.0 * 0.5);
-            hipLaunchKernelGGL(nms_reduce_kernel, dim3(nseg), dim3(REDUCE_THREADS), smem, stream, mask, counters,
-                               removed_g, cap, words, chunk0, panel_rows, max_keep, keep);
+            ProfScope scope(stream, "nms_reduce", 0.0, (double)nseg * rows_here * 64.0 * rows_here * 8.0 * 0.5);
+            hipLaunchKernelGGL(nms_reduce_kernel, dim3(nseg), dim3(REDUCE_THREADS), 0, stream, mask, counters,
+                               removed_g, keptbits, cap, words, chunk0, panel_rows, max_keep, keep);
+            FD_LAUNCH_CHECK();
+        }
+        const int later = words - (chunk0 + panel_chunks);
+        if (later > 0) {
+            ProfScope scope(stream, "nms_spread", 0.0, (double)nseg * rows_here * 64.0 * later * 8.0);
+            hipLaunchKernelGGL(nms_spread_kernel, dim3(ceil_div(later, 256), ceil_div(panel_chunks, SPREAD_CHUNKS), nseg),
+                               dim3(256), 0, stream, mask, counters, keptbits, removed_g, words, chunk0, panel_rows,
+                               max_keep);
             FD_LAUNCH_CHECK();
         }
     }
     return FD_OK;
 }
+
 template int nms_sorted<float>(fd_ctx*, const float*, int32_t*, int, int, float, int, int32_t*, hipStream_t);
 template int nms_sorted<double>(fd_ctx*, const double*, int32_t*, int, int, double, int, int32_t*, hipStream_t);
 
