@@ -289,284 +289,6 @@ __global__ __launch_bounds__(256, 2) void conv_split_kernel(SplitKArgs a) {
 }
 
 // ---------------------------------------------------------------------------------
-// Direct-to-LDS variant (everything but the stem).  Both operand tiles are fetched with
-// `buffer_load_dwordx4 ... lds`: no staging registers, no ds_write, and padding taps / rows
-// beyond M are zero-filled by the buffer's range check (their offset is pushed out of range).
-// One wave instruction fills 8 rows x 128 B of the LDS image contiguously, so rows cannot be
-// padded; instead the 16-byte chunk c of row r is stored at chunk position c ^ ((r >> 1) & 7),
-// which makes the fragment reads (16 lanes, 16 distinct rows, same chunk) conflict-free.  The
-// permutation is applied on the global source address of each lane and undone when reading.
-template <int BM, int BN, bool S16>
-__global__ __launch_bounds__(256, 2) void conv_split_glds_kernel(SplitKArgs a, unsigned x_bytes, unsigned w_bytes) {
-#if defined(__HIP_DEVICE_COMPILE__)   // buffer-resource builtins exist in device code only; the host pass needs just the stub
-    constexpr int GA = BM / 32, GB = BN / 32;   // 8-row groups per wave per K-step
-    constexpr int MT = BM / 64, NT = BN / 64;
-    constexpr int STAGE = (BM + BN) * 32;        // dwords per pipeline stage
-    constexpr int WN = BN / 2;
-    constexpr int LDC = WN + 4;
-    constexpr int EPI = 4 * 32 * LDC;            // epilogue staging, dwords
-    constexpr int SMEM = (2 * STAGE > EPI) ? 2 * STAGE : EPI;
-    __shared__ __attribute__((aligned(16))) float smem[SMEM];
-
-    // the wave index is uniform: keeping it in a scalar register makes every LDS destination
-    // address of the loads below scalar arithmetic
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
-    int wgid;
-    {
-        const int nwg = gridDim.x, bid = blockIdx.x;
-        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
-        wgid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-    }
-    const int tile_n = wgid % a.tiles_n, tile_m = wgid / a.tiles_n;
-
-    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, x_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, w_bytes, 0x00020000);
-    constexpr unsigned OOB = 0x80000000u;        // beyond any tensor this kernel is launched for
-
-    // this lane's row inside an 8-row group and the chunk position it fills
-    const int lrow = lane >> 3, lpos = lane & 7;
-    int hi0[GA], wi0[GA];
-    unsigned abase[GA];                          // byte offset of the row's window origin (+ its chunk)
-    bool mval[GA];
-#pragma unroll
-    for (int i = 0; i < GA; ++i) {
-        const int row = (wave + 4 * i) * 8 + lrow;                  // row inside the tile
-        const int chunk = lpos ^ ((row >> 1) & 7);
-        const int m = tile_m * BM + row;
-        mval[i] = m < a.M;
-        const int mm = mval[i] ? m : 0;
-        const int hw = a.Ho * a.Wo;
-        const int img = mm / hw;
-        const int rem = mm - img * hw;
-        const int ho = rem / a.Wo;
-        const int wo = rem - ho * a.Wo;
-        hi0[i] = ho * a.stride - a.pad;
-        wi0[i] = wo * a.stride - a.pad;
-        abase[i] = (unsigned)(((img * a.H + hi0[i]) * a.W + wi0[i]) * a.Cin * 4 + chunk * 16);
-    }
-    unsigned bvo[GB];                            // weights: per-lane offset, constant over the K loop
-#pragma unroll
-    for (int i = 0; i < GB; ++i) {
-        const int row = (wave + 4 * i) * 8 + lrow;
-        const int chunk = lpos ^ ((row >> 1) & 7);
-        bvo[i] = (unsigned)((tile_n * BN + row) * a.K * 4 + chunk * 16);
-    }
-    int kh = 0, kw = 0, coff = 0;
-    const int nk = a.K / SBK;
-
-    // Per-lane offsets of the activation rows change only with the filter tap (validity of the
-    // tap for the row's window); the channel position inside the tap and the K position in the
-    // weights are uniform and travel in the instruction's scalar offset.
-    unsigned avo[GA];
-#define FD_TAP()                                                                                  \
-    do {                                                                                          \
-        const unsigned toff_ = (unsigned)((kh * a.W + kw) * a.Cin * 4);                           \
-        _Pragma("unroll") for (int i = 0; i < GA; ++i) {                                          \
-            const int hi_ = hi0[i] + kh, wi_ = wi0[i] + kw;                                       \
-            const bool ok_ = mval[i] && (unsigned)hi_ < (unsigned)a.H && (unsigned)wi_ < (unsigned)a.W; \
-            avo[i] = ok_ ? abase[i] + toff_ : OOB;                                                \
-        }                                                                                         \
-    } while (0)
-
-#define FD_ISSUE(KT, STG)                                                                         \
-    do {                                                                                          \
-        float* sa_ = smem + (STG) * STAGE;                                                        \
-        _Pragma("unroll") for (int i = 0; i < GA; ++i)                                            \
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(                                             \
-                xr, (__attribute__((address_space(3))) void*)(sa_ + (wave + 4 * i) * 256), 16, avo[i], coff * 4, 0, 0); \
-        _Pragma("unroll") for (int i = 0; i < GB; ++i)                                            \
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(                                             \
-                wr, (__attribute__((address_space(3))) void*)(sa_ + BM * 32 + (wave + 4 * i) * 256), 16, \
-                bvo[i], (KT) * 128, 0, 0);                                                        \
-        coff += SBK;                                                                              \
-        if (coff >= a.Cin) {                                                                      \
-            coff = 0;                                                                             \
-            if (++kw == a.KW) { kw = 0; ++kh; }                                                   \
-            FD_TAP();                                                                             \
-        }                                                                                         \
-    } while (0)
-
-    // S16: 16x16x32 blocks (one fragment read covers the whole K-step), else 32x32x16 blocks
-    constexpr int AM = S16 ? MT * 2 : MT, AN = S16 ? NT * 2 : NT;
-    typedef typename std::conditional<S16, f32x4, f32x16>::type acc_t;
-    constexpr int AR = S16 ? 4 : 16;
-    acc_t acc[AM][AN];
-#pragma unroll
-    for (int mi = 0; mi < AM; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < AN; ++ni)
-#pragma unroll
-            for (int r = 0; r < AR; ++r) acc[mi][ni][r] = 0.f;
-
-    // fragment addressing: row R, chunk c (hi chunks 0..3, lo chunks 4..7 of the 128-byte row)
-    // stored at position c ^ ((R >> 1) & 7).  32x32x16: R & 31 == lane & 31, c = part * 4 +
-    // kg * 2 + (lane >> 5).  16x16x32: R & 15 == lane & 15, c = part * 4 + (lane >> 4).  Either
-    // way the byte offsets per operand are fixed; stage and block index are immediates.
-    const int frow = S16 ? (lane & 15) : (lane & 31), fh = S16 ? (lane >> 4) : (lane >> 5);
-    const int sw = (frow >> 1) & 7;
-    const char* sbase = reinterpret_cast<const char*>(smem);
-    int a_off[2][2], b_off[2][2];
-#pragma unroll
-    for (int kg = 0; kg < 2; ++kg)
-#pragma unroll
-        for (int part = 0; part < 2; ++part) {
-            const int pos = ((S16 ? part * 4 + fh : part * 4 + kg * 2 + fh) ^ sw) * 16;
-            a_off[kg][part] = (wm * (BM / 2) + frow) * 128 + pos;
-            b_off[kg][part] = (BM + wn * (BN / 2) + frow) * 128 + pos;
-        }
-
-#define FD_STEP(CUR, KT)                                                                          \
-    do {                                                                                          \
-        if ((KT) + 1 < nk) FD_ISSUE((KT) + 1, (CUR) ^ 1);                                         \
-        if constexpr (S16) {                                                                      \
-            f16x8 ah[AM], al[AM], bh[AN], bl[AN];                                                 \
-            _Pragma("unroll") for (int mi = 0; mi < AM; ++mi) {                                   \
-                ah[mi] = *reinterpret_cast<const f16x8*>(sbase + a_off[0][0] + (CUR) * STAGE * 4 + mi * 2048); \
-                al[mi] = *reinterpret_cast<const f16x8*>(sbase + a_off[0][1] + (CUR) * STAGE * 4 + mi * 2048); \
-            }                                                                                     \
-            _Pragma("unroll") for (int ni = 0; ni < AN; ++ni) {                                   \
-                bh[ni] = *reinterpret_cast<const f16x8*>(sbase + b_off[0][0] + (CUR) * STAGE * 4 + ni * 2048); \
-                bl[ni] = *reinterpret_cast<const f16x8*>(sbase + b_off[0][1] + (CUR) * STAGE * 4 + ni * 2048); \
-            }                                                                                     \
-            _Pragma("unroll") for (int mi = 0; mi < AM; ++mi)                                     \
-                _Pragma("unroll") for (int ni = 0; ni < AN; ++ni) {                               \
-                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[mi], bh[ni], acc[mi][ni], 0, 0, 0); \
-                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[mi], bl[ni], acc[mi][ni], 0, 0, 0); \
-                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[mi], bh[ni], acc[mi][ni], 0, 0, 0); \
-                }                                                                                 \
-        } else                                                                                    \
-        _Pragma("unroll") for (int kg = 0; kg < 2; ++kg) {                                        \
-            f16x8 ah[MT], al[MT], bh[NT], bl[NT];                                                 \
-            _Pragma("unroll") for (int mi = 0; mi < MT; ++mi) {                                   \
-                ah[mi] = *reinterpret_cast<const f16x8*>(sbase + a_off[kg][0] + (CUR) * STAGE * 4 + mi * 4096); \
-                al[mi] = *reinterpret_cast<const f16x8*>(sbase + a_off[kg][1] + (CUR) * STAGE * 4 + mi * 4096); \
-            }                                                                                     \
-            _Pragma("unroll") for (int ni = 0; ni < NT; ++ni) {                                   \
-                bh[ni] = *reinterpret_cast<const f16x8*>(sbase + b_off[kg][0] + (CUR) * STAGE * 4 + ni * 4096); \
-                bl[ni] = *reinterpret_cast<const f16x8*>(sbase + b_off[kg][1] + (CUR) * STAGE * 4 + ni * 4096); \
-            }                                                                                     \
-            _Pragma("unroll") for (int mi = 0; mi < MT; ++mi)                                     \
-                _Pragma("unroll") for (int ni = 0; ni < NT; ++ni) {                               \
-                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[mi], bh[ni], acc[mi][ni], 0, 0, 0); \
-                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mi], bl[ni], acc[mi][ni], 0, 0, 0); \
-                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mi], bh[ni], acc[mi][ni], 0, 0, 0); \
-                }                                                                                 \
-        }                                                                                         \
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                          \
-        __syncthreads();                                                                          \
-    } while (0)
-
-    FD_TAP();
-    FD_ISSUE(0, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    for (int kt = 0; kt < nk; kt += 2) {
-        FD_STEP(0, kt);
-        if (kt + 1 < nk) FD_STEP(1, kt + 1);
-    }
-#undef FD_STEP
-#undef FD_TAP
-#undef FD_ISSUE
-
-    // epilogue (same as the register-staged kernel; the staging slice lives at the start of smem)
-    constexpr int L8 = WN / 8;
-    constexpr int RPP = 64 / L8;
-    constexpr int PASSES = 32 / RPP;
-    float* Cs = smem + wave * (32 * LDC);
-    const int erow = lane / L8, ecol = (lane % L8) * 8;
-    const int gcol = tile_n * BN + wn * WN + ecol;
-    const bool col_ok = gcol < a.Cout;
-    constexpr int CB = S16 ? 16 : 32;         // columns per accumulator block
-    float bias_v[AN];
-#pragma unroll
-    for (int ni = 0; ni < AN; ++ni) {
-        const int col = tile_n * BN + wn * WN + ni * CB + (lane & (CB - 1));
-        bias_v[ni] = (a.bias && col < a.Cout) ? a.bias[col] : 0.f;
-    }
-    f32x4 ps0 = {1.f, 1.f, 1.f, 1.f}, ps1 = ps0, pt0 = {0.f, 0.f, 0.f, 0.f}, pt1 = pt0;
-    const bool post = a.ysplit && a.post_scale && col_ok;
-    if (post) {
-        ps0 = *reinterpret_cast<const f32x4*>(a.post_scale + gcol);
-        ps1 = *reinterpret_cast<const f32x4*>(a.post_scale + gcol + 4);
-        pt0 = *reinterpret_cast<const f32x4*>(a.post_shift + gcol);
-        pt1 = *reinterpret_cast<const f32x4*>(a.post_shift + gcol + 4);
-    }
-#pragma unroll
-    for (int mi = 0; mi < MT; ++mi) {
-        const int grow0 = tile_m * BM + wm * (BM / 2) + mi * 32;
-        f32x4 res0[PASSES], res1[PASSES];
-        if (a.res) {
-#pragma unroll
-            for (int ps = 0; ps < PASSES; ++ps) {
-                const int row = grow0 + ps * RPP + erow;
-                res0[ps] = f32x4{0.f, 0.f, 0.f, 0.f};
-                res1[ps] = res0[ps];
-                if (row < a.M && col_ok) {
-                    const float* rp = a.res + (size_t)row * a.Cout + gcol;
-                    res0[ps] = *reinterpret_cast<const f32x4*>(rp);
-                    res1[ps] = *reinterpret_cast<const f32x4*>(rp + 4);
-                }
-            }
-        }
-        __syncthreads();
-        if constexpr (S16) {
-            // 16x16 block: column = lane & 15, row = (lane >> 4) * 4 + register
-#pragma unroll
-            for (int mb = 0; mb < 2; ++mb)
-#pragma unroll
-                for (int ni = 0; ni < AN; ++ni)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        float v = acc[mi * 2 + mb][ni][r] * a.w_inv_scale + bias_v[ni];
-                        if (a.relu) v = fmaxf(v, 0.f);
-                        Cs[(mb * 16 + (lane >> 4) * 4 + r) * LDC + ni * 16 + (lane & 15)] = v;
-                    }
-        } else {
-#pragma unroll
-            for (int ni = 0; ni < AN; ++ni)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    float v = acc[mi][ni][r] * a.w_inv_scale + bias_v[ni];
-                    if (a.relu) v = fmaxf(v, 0.f);
-                    Cs[((r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * LDC + ni * 32 + (lane & 31)] = v;
-                }
-        }
-        __syncthreads();
-#pragma unroll
-        for (int ps = 0; ps < PASSES; ++ps) {
-            const int lrow2 = ps * RPP + erow;
-            const int row = grow0 + lrow2;
-            f32x4 v0 = *reinterpret_cast<const f32x4*>(&Cs[lrow2 * LDC + ecol]);
-            f32x4 v1 = *reinterpret_cast<const f32x4*>(&Cs[lrow2 * LDC + ecol + 4]);
-            if (a.res) { v0 += res0[ps]; v1 += res1[ps]; }
-            if (row < a.M && col_ok) {
-                if (a.y32) {
-                    float* yp = a.y32 + (size_t)row * a.Cout + gcol;
-                    *reinterpret_cast<f32x4*>(yp) = v0;
-                    *reinterpret_cast<f32x4*>(yp + 4) = v1;
-                }
-                if (a.ysplit) {
-                    if (post) {
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            v0[j] = fmaxf(v0[j] * ps0[j] + pt0[j], 0.f);
-                            v1[j] = fmaxf(v1[j] * ps1[j] + pt1[j], 0.f);
-                        }
-                    }
-                    f16x8 hi, lo;
-                    split8(v0, v1, hi, lo);
-                    uint8_t* sp = a.ysplit + (size_t)row * a.Cout * 4 + split_offset(gcol);
-                    *reinterpret_cast<f16x8*>(sp) = hi;
-                    *reinterpret_cast<f16x8*>(sp + 64) = lo;
-                }
-            }
-        }
-    }
-#endif
-}
-
-// ---------------------------------------------------------------------------------
 // Register-staged activations on the same LDS image as the direct-to-LDS kernel (swizzled
 // 128-byte rows, 16x16x32 blocks, weights by LDS-DMA).  Two uses:
 //   REG_PRE  - the input is float32; BatchNorm+ReLU and the fp16 split happen between the
@@ -703,6 +425,188 @@ __device__ __forceinline__ void split_epilogue16(const SplitKArgs& a, float* sme
             }
         }
     }
+}
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// ---------------------------------------------------------------------------------
+// Direct-to-LDS kernel (every layer whose input is already split).  Both operand tiles are
+// fetched with `buffer_load_dwordx4 ... lds`: no staging registers, no ds_write, and padding
+// taps / rows beyond M are zero-filled by the buffer's range check (their offset is pushed out
+// of range).  One wave instruction fills 8 rows x 128 B of the LDS image contiguously, so rows
+// cannot be padded; instead the 16-byte chunk c of row r is stored at chunk position
+// c ^ ((r >> 1) & 7), which makes the fragment reads conflict-free.  The permutation is applied
+// on the global source address of each lane and undone when reading.
+// NS pipeline stages: a K-step's loads are issued NS-1 steps before their use.  Two stages for
+// the 128x128 tile (two workgroups per CU share 160 KB of LDS); the small tiles, whose grids
+// are latency-bound, run three or four.
+template <int BM, int BN, int NS>
+__global__ __launch_bounds__(256, 2) void conv_split_glds_kernel(SplitKArgs a, unsigned x_bytes, unsigned w_bytes) {
+#if defined(__HIP_DEVICE_COMPILE__)   // buffer-resource builtins exist in device code only; the host pass needs just the stub
+    using T = SplitTile<BM, BN>;
+    constexpr int GA = BM / 32, GB = BN / 32;   // 8-row groups per wave per K-step
+    constexpr int PIECES = GA + GB;             // LDS-DMA instructions per wave and stage
+    constexpr int STAGE = T::STAGE;
+    constexpr int SMEM = (NS * STAGE > T::EPI) ? NS * STAGE : T::EPI;
+    static_assert(NS >= 2 && NS <= 4 && (NS - 2) * PIECES < 64, "pipeline depth");
+    __shared__ __attribute__((aligned(16))) float smem[SMEM];
+
+    // the wave index is uniform: keeping it in a scalar register makes every LDS destination
+    // address of the loads below scalar arithmetic
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    int wgid;
+    {
+        const int nwg = gridDim.x, bid = blockIdx.x;
+        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+        wgid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    }
+    const int tile_n = wgid % a.tiles_n, tile_m = wgid / a.tiles_n;
+
+    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, w_bytes, 0x00020000);
+    constexpr unsigned OOB = 0x80000000u;        // beyond any tensor this kernel is launched for
+
+    // this lane's row inside an 8-row group and the chunk position it fills
+    const int lrow = lane >> 3, lpos = lane & 7;
+    int hi0[GA], wi0[GA];
+    unsigned abase[GA];                          // byte offset of the row's window origin (+ its chunk)
+    bool mval[GA];
+#pragma unroll
+    for (int i = 0; i < GA; ++i) {
+        const int row = (wave + 4 * i) * 8 + lrow;                  // row inside the tile
+        const int chunk = lpos ^ ((row >> 1) & 7);
+        const int m = tile_m * BM + row;
+        mval[i] = m < a.M;
+        const int mm = mval[i] ? m : 0;
+        const int hw = a.Ho * a.Wo;
+        const int img = mm / hw;
+        const int rem = mm - img * hw;
+        const int ho = rem / a.Wo;
+        const int wo = rem - ho * a.Wo;
+        hi0[i] = ho * a.stride - a.pad;
+        wi0[i] = wo * a.stride - a.pad;
+        abase[i] = (unsigned)(((img * a.H + hi0[i]) * a.W + wi0[i]) * a.Cin * 4 + chunk * 16);
+    }
+    unsigned bvo[GB];                            // weights: per-lane offset, constant over the K loop
+#pragma unroll
+    for (int i = 0; i < GB; ++i) {
+        const int row = (wave + 4 * i) * 8 + lrow;
+        const int chunk = lpos ^ ((row >> 1) & 7);
+        bvo[i] = (unsigned)((tile_n * BN + row) * a.K * 4 + chunk * 16);
+    }
+    int kh = 0, kw = 0, coff = 0;
+    const int nk = a.K / SBK;
+
+    // Per-lane offsets of the activation rows change only with the filter tap (validity of the
+    // tap for the row's window); the channel position inside the tap and the K position in the
+    // weights are uniform and travel in the instruction's scalar offset.
+    unsigned avo[GA];
+#define FD_TAP()                                                                                  \
+    do {                                                                                          \
+        const unsigned toff_ = (unsigned)((kh * a.W + kw) * a.Cin * 4);                           \
+        _Pragma("unroll") for (int i = 0; i < GA; ++i) {                                          \
+            const int hi_ = hi0[i] + kh, wi_ = wi0[i] + kw;                                       \
+            const bool ok_ = mval[i] && (unsigned)hi_ < (unsigned)a.H && (unsigned)wi_ < (unsigned)a.W; \
+            avo[i] = ok_ ? abase[i] + toff_ : OOB;                                                \
+        }                                                                                         \
+    } while (0)
+
+#define FD_ISSUE(KT, STG)                                                                         \
+    do {                                                                                          \
+        float* sa_ = smem + (STG) * STAGE;                                                        \
+        _Pragma("unroll") for (int i = 0; i < GA; ++i)                                            \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(                                             \
+                xr, (__attribute__((address_space(3))) void*)(sa_ + (wave + 4 * i) * 256), 16, avo[i], coff * 4, 0, 0); \
+        _Pragma("unroll") for (int i = 0; i < GB; ++i)                                            \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(                                             \
+                wr, (__attribute__((address_space(3))) void*)(sa_ + BM * 32 + (wave + 4 * i) * 256), 16, \
+                bvo[i], (KT) * 128, 0, 0);                                                        \
+        coff += SBK;                                                                              \
+        if (coff >= a.Cin) {                                                                      \
+            coff = 0;                                                                             \
+            if (++kw == a.KW) { kw = 0; ++kh; }                                                   \
+            FD_TAP();                                                                             \
+        }                                                                                         \
+    } while (0)
+
+    // wait until at most AHEAD later stages of this wave's loads are still in flight
+#define FD_WAIT(AHEAD)                                                                            \
+    do {                                                                                          \
+        const int ahead_ = (AHEAD);                                                               \
+        if (NS >= 4 && ahead_ >= 2) wait_vmcnt<(NS >= 4 ? 2 * PIECES : 0)>();                     \
+        else if (NS >= 3 && ahead_ >= 1) wait_vmcnt<(NS >= 3 ? PIECES : 0)>();                    \
+        else wait_vmcnt<0>();                                                                     \
+    } while (0)
+
+    f32x4 acc[T::AM][T::AN];
+#pragma unroll
+    for (int mi = 0; mi < T::AM; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < T::AN; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // fragment addressing (16x16x32 blocks): row R with R & 15 == lane & 15, chunk
+    // part * 4 + (lane >> 4) (hi chunks 0..3, lo chunks 4..7) stored at position
+    // chunk ^ ((R >> 1) & 7); stage and block index are immediates
+    const int frow = lane & 15, fh = lane >> 4;
+    const int sw = (frow >> 1) & 7;
+    const char* sbase = reinterpret_cast<const char*>(smem);
+    int a_off[2], b_off[2];
+#pragma unroll
+    for (int part = 0; part < 2; ++part) {
+        const int pos = ((part * 4 + fh) ^ sw) * 16;
+        a_off[part] = (wm * (BM / 2) + frow) * 128 + pos;
+        b_off[part] = (BM + wn * (BN / 2) + frow) * 128 + pos;
+    }
+
+#define FD_STEP(CUR, KT)                                                                          \
+    do {                                                                                          \
+        if ((KT) + NS - 1 < nk) FD_ISSUE((KT) + NS - 1, ((CUR) + NS - 1) % NS);                   \
+        split_mma_step<BM, BN>(sbase + (CUR) * STAGE * 4, a_off, b_off, acc);                     \
+        FD_WAIT(min(NS - 2, nk - 2 - (KT)));                                                      \
+        __syncthreads();                                                                          \
+    } while (0)
+
+    FD_TAP();
+#pragma unroll
+    for (int st = 0; st < NS - 1; ++st)
+        if (st < nk) FD_ISSUE(st, st);
+    FD_WAIT(min(NS - 2, nk - 1));
+    __syncthreads();
+    for (int kt = 0; kt < nk; kt += NS) {
+        FD_STEP(0, kt);
+        if (kt + 1 < nk) FD_STEP(1, kt + 1);
+        if constexpr (NS > 2) {
+            if (kt + 2 < nk) FD_STEP(2, kt + 2);
+        }
+        if constexpr (NS > 3) {
+            if (kt + 3 < nk) FD_STEP(3, kt + 3);
+        }
+    }
+#undef FD_STEP
+#undef FD_WAIT
+#undef FD_ISSUE
+#undef FD_TAP
+    split_epilogue16<BM, BN>(a, smem, tile_m, tile_n, wave, lane, acc);
+#endif
+}
+
+template <int BM, int BN, int NS>
+static int launch_split_glds(const SplitKArgs& a, size_t x_bytes, size_t w_bytes, hipStream_t stream) {
+    static const std::string name = std::string("conv_split_") + std::to_string(BM) + "x" + std::to_string(BN);
+    ProfScope scope(stream, name.c_str(), 2.0 * a.M * a.Cout * (double)a.K,
+                    (double)a.H * a.W * (a.M / ((double)a.Ho * a.Wo)) * 4.0 * a.Cin + 4.0 * a.Cout * (double)a.K +
+                        4.0 * a.M * a.Cout * ((a.res ? 1.0 : 0.0) + (a.y32 ? 1.0 : 0.0) + (a.ysplit ? 1.0 : 0.0)));
+    SplitKArgs k = a;
+    const int tiles_m = ceil_div(a.M, BM);
+    k.tiles_n = ceil_div(a.Cout, BN);
+    hipLaunchKernelGGL((conv_split_glds_kernel<BM, BN, NS>), dim3(tiles_m * k.tiles_n), dim3(256), 0, stream, k,
+                       (unsigned)x_bytes, (unsigned)w_bytes);
+    FD_LAUNCH_CHECK();
+    return FD_OK;
 }
 
 template <int BM, int BN, int MODE>
@@ -891,38 +795,6 @@ static int launch_split_reg(const SplitKArgs& a, size_t x_bytes, size_t w_bytes,
     return FD_OK;
 }
 
-// Block shape of the direct-to-LDS kernels: v_mfma_f32_16x16x32_f16 unless FD_MFMA_SHAPE=32 is
-// set in the environment (read once).  Both shapes issue the same cycles per FLOP and read the
-// same LDS bytes, but under sustained load the chip holds a higher clock on the 16x16x32 form:
-// measured +4.6 % frames/s on the whole 1080p pipeline.  The switch exists to repeat that
-// comparison.
-static bool use_shape16() {
-    static const bool v = [] {
-        const char* e = getenv("FD_MFMA_SHAPE");
-        return !(e && atoi(e) == 32);
-    }();
-    return v;
-}
-
-template <int BM, int BN>
-static int launch_split_glds(const SplitKArgs& a, size_t x_bytes, size_t w_bytes, hipStream_t stream) {
-    static const std::string name = std::string("conv_split_") + std::to_string(BM) + "x" + std::to_string(BN);
-    ProfScope scope(stream, name.c_str(), 2.0 * a.M * a.Cout * (double)a.K,
-                    (double)a.H * a.W * (a.M / ((double)a.Ho * a.Wo)) * 4.0 * a.Cin + 4.0 * a.Cout * (double)a.K +
-                        4.0 * a.M * a.Cout * ((a.res ? 1.0 : 0.0) + (a.y32 ? 1.0 : 0.0) + (a.ysplit ? 1.0 : 0.0)));
-    SplitKArgs k = a;
-    const int tiles_m = ceil_div(a.M, BM);
-    k.tiles_n = ceil_div(a.Cout, BN);
-    if (use_shape16())
-        hipLaunchKernelGGL((conv_split_glds_kernel<BM, BN, true>), dim3(tiles_m * k.tiles_n), dim3(256), 0, stream, k,
-                           (unsigned)x_bytes, (unsigned)w_bytes);
-    else
-        hipLaunchKernelGGL((conv_split_glds_kernel<BM, BN, false>), dim3(tiles_m * k.tiles_n), dim3(256), 0, stream,
-                           k, (unsigned)x_bytes, (unsigned)w_bytes);
-    FD_LAUNCH_CHECK();
-    return FD_OK;
-}
-
 template <int BM, int BN, bool STEM, bool PRE = false>
 static int launch_split(const SplitKArgs& a, hipStream_t stream) {
     static const std::string name = std::string("conv_split_") + std::to_string(BM) + "x" + std::to_string(BN) +
@@ -984,9 +856,9 @@ static int split_conv_dispatch(const SplitConvParams& p, const void* x_split, co
         return launch_split<64, 64, false, true>(a, stream);
     }
     if (small) {
-        if (s.cout > 64 && t128 >= 384) return launch_split_glds<128, 128>(a, x_bytes, w_bytes, stream);
-        if (t12864 >= 384) return launch_split_glds<128, 64>(a, x_bytes, w_bytes, stream);
-        return launch_split_glds<64, 64>(a, x_bytes, w_bytes, stream);
+        if (s.cout > 64 && t128 >= 384) return launch_split_glds<128, 128, 2>(a, x_bytes, w_bytes, stream);
+        if (t12864 >= 384) return launch_split_glds<128, 64, 3>(a, x_bytes, w_bytes, stream);
+        return launch_split_glds<64, 64, 4>(a, x_bytes, w_bytes, stream);
     }
     if (s.cout > 64 && t128 >= 384) return launch_split<128, 128, false>(a, stream);
     if (t12864 >= 384) return launch_split<128, 64, false>(a, stream);
