@@ -441,8 +441,8 @@ __device__ __forceinline__ void wait_vmcnt() {
 // c ^ ((r >> 1) & 7), which makes the fragment reads conflict-free.  The permutation is applied
 // on the global source address of each lane and undone when reading.
 // NS pipeline stages: a K-step's loads are issued NS-1 steps before their use.  Two stages for
-// the 128x128 tile (two workgroups per CU share 160 KB of LDS); the small tiles, whose grids
-// are latency-bound, run three or four.
+// the 128-row tiles (two workgroups per CU share 160 KB of LDS; three stages measured slower on
+// the 128x64 tile), four for the 64x64 tile, whose small grids leave one wave per SIMD.
 template <int BM, int BN, int NS>
 __global__ __launch_bounds__(256, 2) void conv_split_glds_kernel(SplitKArgs a, unsigned x_bytes, unsigned w_bytes) {
 #if defined(__HIP_DEVICE_COMPILE__)   // buffer-resource builtins exist in device code only; the host pass needs just the stub
@@ -857,7 +857,7 @@ static int split_conv_dispatch(const SplitConvParams& p, const void* x_split, co
     }
     if (small) {
         if (s.cout > 64 && t128 >= 384) return launch_split_glds<128, 128, 2>(a, x_bytes, w_bytes, stream);
-        if (t12864 >= 384) return launch_split_glds<128, 64, 3>(a, x_bytes, w_bytes, stream);
+        if (t12864 >= 384) return launch_split_glds<128, 64, 2>(a, x_bytes, w_bytes, stream);
         return launch_split_glds<64, 64, 4>(a, x_bytes, w_bytes, stream);
     }
     if (s.cout > 64 && t128 >= 384) return launch_split<128, 128, false>(a, stream);
