@@ -39,6 +39,13 @@ int to_split(const float* x, long long rows, int channels, const float* scale, c
 int stage_input_split(const uint8_t* frames, int batch, int h, int w, const InputNorm& norm, void* y,
                       hipStream_t stream);
 
+// The 7x7/2 stem (bn0+ReLU folded) and the 3x3/2 max-pool in one kernel: staged split image ->
+// pooled split activations with relu(x * post_scale + post_shift) applied (and float32 pooled
+// values when y32 is given).
+int stem_pool_forward(const SplitConvParams& p, const void* staged_split, int batch, int h, int w,
+                      const float* post_scale, const float* post_shift, float* y32, void* ysplit,
+                      hipStream_t stream);
+
 int maxpool_3x3s2_split(const float* x, int batch, int h, int w, int c, const float* scale, const float* shift,
                         float* y32, void* ysplit, hipStream_t stream);
 

@@ -1036,6 +1036,231 @@ __global__ __launch_bounds__(256) void maxpool_split_kernel(const float* __restr
     }
 }
 
+// ---------------------------------------------------------------------------------
+// Stem convolution (7x7/2, bn0+ReLU folded) fused with the 3x3/2 max-pool that follows it.
+// A workgroup owns PH x PW pooled pixels of one image.  Their windows cover a patch of
+// (2 PH + 1) x (2 PW + 1) convolution outputs (one-pixel halo, recomputed by the neighbouring
+// workgroups: 15 % extra MFMA work), which is the M tile of the GEMM: row m of the tile is
+// patch pixel (m / CW, m % CW).  The patch stays in LDS as float32; the pooled values leave as
+// the split activation of the first residual unit (its bn1+ReLU applied) and, on request, as
+// float32.  Patch positions outside the convolution's output are 0, which cannot win a maximum
+// of post-ReLU values.  This removes the write and the re-read of the 64-channel full-resolution
+// tensor (2.1 GB per 8 frames at 1080p).
+struct StemPoolArgs {
+    const uint8_t* x;        // split staged image [B][H][W][4 hi | 4 lo]
+    const uint8_t* w;        // split packed stem weights [64][7][8][4]
+    const float* bias;       // bn0 shift
+    const float* post_scale; // bn1 of the first unit, applied to the split output
+    const float* post_shift;
+    float* y32;              // pooled float32 [B][Hp][Wp][64] or NULL
+    uint8_t* ysplit;         // pooled split output
+    float w_inv_scale;
+    int H, W, Ho, Wo, Hp, Wp, tiles_y, tiles_x;
+};
+
+template <int PH, int PW>
+__global__ __launch_bounds__(256, 2) void stem_pool_kernel(StemPoolArgs a, unsigned x_bytes, unsigned w_bytes) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    constexpr int BM = 256, BN = 64, COUT = 64;
+    constexpr int CH = 2 * PH + 1, CW = 2 * PW + 1;   // convolution patch
+    static_assert(CH * CW <= BM, "patch must fit the M tile");
+    using T = SplitTile<BM, BN>;
+    constexpr int RA = BM / 32, GB = BN / 32;
+    constexpr int STAGE = T::STAGE;
+    constexpr int LDP = COUT + 4;                     // patch row pitch in floats
+    constexpr int SMEM = (2 * STAGE > BM * LDP) ? 2 * STAGE : BM * LDP;
+    __shared__ __attribute__((aligned(16))) float smem[SMEM];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int tx = blockIdx.x % a.tiles_x, ty = (blockIdx.x / a.tiles_x) % a.tiles_y;
+    const int img = blockIdx.x / (a.tiles_x * a.tiles_y);
+    const int oy0 = 2 * PH * ty - 1, ox0 = 2 * PW * tx - 1;     // patch origin in convolution-output coordinates
+
+    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, w_bytes, 0x00020000);
+    constexpr unsigned OOB = 0x80000000u;
+
+    // activations: thread -> patch rows r0 + 32 i, kernel column c4 (k = 4 c4 + c inside a kernel row)
+    const int c4 = tid & 7, r0 = tid >> 3;
+    int hi0[RA], wi0[RA];
+    unsigned abase[RA], a_lds[RA];
+    bool mval[RA];
+#pragma unroll
+    for (int i = 0; i < RA; ++i) {
+        const int row = r0 + 32 * i;
+        const int pr = row / CW, pc = row - pr * CW;
+        const int oy = oy0 + pr, ox = ox0 + pc;
+        mval[i] = row < CH * CW && (unsigned)oy < (unsigned)a.Ho && (unsigned)ox < (unsigned)a.Wo;
+        hi0[i] = oy * 2 - 3;
+        wi0[i] = ox * 2 - 3;
+        abase[i] = (unsigned)(((img * a.H + hi0[i]) * a.W + wi0[i]) * 16 + c4 * 16);
+        a_lds[i] = (unsigned)(row * 128 + (((c4 >> 1) ^ ((row >> 1) & 7)) * 16) + (c4 & 1) * 8);
+    }
+    const int lrow = lane >> 3, lpos = lane & 7;
+    unsigned bvo[GB];
+#pragma unroll
+    for (int i = 0; i < GB; ++i) {
+        const int row = (wave + 4 * i) * 8 + lrow;
+        bvo[i] = (unsigned)(row * 224 * 4 + (lpos ^ ((row >> 1) & 7)) * 16);
+    }
+    constexpr int NK = 7;                             // one K-step per kernel row
+    f32x4 ra[RA];
+
+#define FD_GLOAD(KT, STG)                                                                         \
+    do {                                                                                          \
+        _Pragma("unroll") for (int i = 0; i < RA; ++i) {                                          \
+            const int hi_ = hi0[i] + (KT), wi_ = wi0[i] + c4;                                     \
+            const bool ok_ = mval[i] && (unsigned)hi_ < (unsigned)a.H && (unsigned)wi_ < (unsigned)a.W; \
+            const unsigned vo_ = ok_ ? abase[i] + (unsigned)((KT) * a.W * 16) : OOB;              \
+            ra[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xr, vo_, 0, 0)); \
+        }                                                                                         \
+        float* sa_ = smem + (STG) * STAGE;                                                        \
+        _Pragma("unroll") for (int i = 0; i < GB; ++i)                                            \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(                                             \
+                wr, (__attribute__((address_space(3))) void*)(sa_ + BM * 32 + (wave + 4 * i) * 256), 16, \
+                bvo[i], (KT) * 128, 0, 0);                                                        \
+    } while (0)
+
+#define FD_LSTORE(STG)                                                                            \
+    do {                                                                                          \
+        char* sb_ = reinterpret_cast<char*>(smem) + (STG) * STAGE * 4;                            \
+        _Pragma("unroll") for (int i = 0; i < RA; ++i) {                                          \
+            const float2 p0_ = make_float2(ra[i][0], ra[i][1]), p1_ = make_float2(ra[i][2], ra[i][3]); \
+            *reinterpret_cast<float2*>(sb_ + a_lds[i]) = p0_;                                     \
+            *reinterpret_cast<float2*>(sb_ + (a_lds[i] ^ 64u)) = p1_;                             \
+        }                                                                                         \
+    } while (0)
+
+    f32x4 acc[T::AM][T::AN];
+#pragma unroll
+    for (int mi = 0; mi < T::AM; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < T::AN; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int frow = lane & 15, fh = lane >> 4;
+    const int sw = (frow >> 1) & 7;
+    const char* sbase = reinterpret_cast<const char*>(smem);
+    int a_off[2], b_off[2];
+#pragma unroll
+    for (int part = 0; part < 2; ++part) {
+        const int pos = ((part * 4 + fh) ^ sw) * 16;
+        a_off[part] = (wm * (BM / 2) + frow) * 128 + pos;
+        b_off[part] = (BM + wn * (BN / 2) + frow) * 128 + pos;
+    }
+
+    FD_GLOAD(0, 0);
+    FD_LSTORE(0);
+    wait_vmcnt<0>();
+    __syncthreads();
+#pragma unroll
+    for (int kt = 0; kt < NK; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < NK) FD_GLOAD(kt + 1, cur ^ 1);
+        split_mma_step<BM, BN>(sbase + cur * STAGE * 4, a_off, b_off, acc);
+        if (kt + 1 < NK) FD_LSTORE(cur ^ 1);
+        wait_vmcnt<0>();
+        __syncthreads();
+    }
+#undef FD_GLOAD
+#undef FD_LSTORE
+
+    // the convolution patch, bias + ReLU applied, as float32 rows of LDP floats
+    float* patch = smem;
+    float bias_v[T::AN];
+#pragma unroll
+    for (int ni = 0; ni < T::AN; ++ni) bias_v[ni] = a.bias ? a.bias[wn * 32 + ni * 16 + (lane & 15)] : 0.f;
+#pragma unroll
+    for (int mi = 0; mi < T::AM; ++mi)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = wm * (BM / 2) + mi * 16 + (lane >> 4) * 4 + r;
+            const int pr = row / CW, pc = row - pr * CW;
+            const bool ok = row < CH * CW && (unsigned)(oy0 + pr) < (unsigned)a.Ho &&
+                            (unsigned)(ox0 + pc) < (unsigned)a.Wo;
+#pragma unroll
+            for (int ni = 0; ni < T::AN; ++ni) {
+                const float v = fmaxf(acc[mi][ni][r] * a.w_inv_scale + bias_v[ni], 0.f);
+                patch[row * LDP + wn * 32 + ni * 16 + (lane & 15)] = ok ? v : 0.f;
+            }
+        }
+    __syncthreads();
+
+    // pooling: one item = 8 channels of one pooled pixel
+    for (int item = tid; item < PH * PW * (COUT / 8); item += 256) {
+        const int cg = item & 7, pp = item >> 3;
+        const int ppy = pp / PW, ppx = pp - ppy * PW;
+        const int py = PH * ty + ppy, px = PW * tx + ppx;
+        if (py >= a.Hp || px >= a.Wp) continue;
+        f32x4 m0 = {0.f, 0.f, 0.f, 0.f}, m1 = m0;
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) {
+                const float* q = patch + ((2 * ppy + dy) * CW + 2 * ppx + dx) * LDP + cg * 8;
+                const f32x4 v0 = *reinterpret_cast<const f32x4*>(q), v1 = *reinterpret_cast<const f32x4*>(q + 4);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    m0[j] = fmaxf(m0[j], v0[j]);
+                    m1[j] = fmaxf(m1[j], v1[j]);
+                }
+            }
+        const size_t orow = ((size_t)img * a.Hp + py) * a.Wp + px;
+        const int c = cg * 8;
+        if (a.y32) {
+            float* yp = a.y32 + orow * COUT + c;
+            *reinterpret_cast<f32x4*>(yp) = m0;
+            *reinterpret_cast<f32x4*>(yp + 4) = m1;
+        }
+        if (a.post_scale) {
+            const f32x4 s0 = *reinterpret_cast<const f32x4*>(a.post_scale + c);
+            const f32x4 s1 = *reinterpret_cast<const f32x4*>(a.post_scale + c + 4);
+            const f32x4 t0 = *reinterpret_cast<const f32x4*>(a.post_shift + c);
+            const f32x4 t1 = *reinterpret_cast<const f32x4*>(a.post_shift + c + 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                m0[j] = fmaxf(m0[j] * s0[j] + t0[j], 0.f);
+                m1[j] = fmaxf(m1[j] * s1[j] + t1[j], 0.f);
+            }
+        }
+        f16x8 hi, lo;
+        split8(m0, m1, hi, lo);
+        uint8_t* sp = a.ysplit + orow * COUT * 4 + split_offset(c);
+        *reinterpret_cast<f16x8*>(sp) = hi;
+        *reinterpret_cast<f16x8*>(sp + 64) = lo;
+    }
+#endif
+}
+
+int stem_pool_forward(const SplitConvParams& p, const void* staged_split, int batch, int h, int w,
+                      const float* post_scale, const float* post_shift, float* y32, void* ysplit,
+                      hipStream_t stream) {
+    const ConvShape& s = p.s;
+    FD_REQUIRE(staged_split && p.w && ysplit, "stem+pool: NULL tensor");
+    FD_REQUIRE(s.cin == 4 && s.kwp == 8 && s.kh == 7 && s.kw == 7 && s.stride == 2 && s.pad == 3 && s.cout == 64 &&
+                   p.relu,
+               "stem+pool: this kernel is the 7x7/2 stem with 64 output channels and ReLU");
+    constexpr int PH = 5, PW = 11;
+    StemPoolArgs a;
+    a.x = static_cast<const uint8_t*>(staged_split);
+    a.w = static_cast<const uint8_t*>(p.w);
+    a.bias = p.bias; a.post_scale = post_scale; a.post_shift = post_shift;
+    a.y32 = y32; a.ysplit = static_cast<uint8_t*>(ysplit); a.w_inv_scale = p.w_inv_scale;
+    a.H = h; a.W = w; a.Ho = s.out_h(h); a.Wo = s.out_w(w);
+    a.Hp = (a.Ho + 2 - 3) / 2 + 1; a.Wp = (a.Wo + 2 - 3) / 2 + 1;
+    a.tiles_y = ceil_div(a.Hp, PH); a.tiles_x = ceil_div(a.Wp, PW);
+    const size_t x_bytes = (size_t)batch * h * w * 16, w_bytes = s.packed_floats() * 4;
+    FD_REQUIRE(x_bytes < (1ull << 31), "stem+pool: staged batch too large for 32-bit offsets");
+    const long long grid = (long long)batch * a.tiles_y * a.tiles_x;
+    FD_REQUIRE(grid < (1ll << 31), "stem+pool: too many tiles");
+    ProfScope scope(stream, "stem_pool", 2.0 * batch * a.Ho * a.Wo * 64.0 * 147.0,
+                    16.0 * batch * h * w + 4.0 * 64.0 * 224.0 +
+                        256.0 * batch * a.Hp * a.Wp * ((y32 ? 1.0 : 0.0) + 1.0));
+    hipLaunchKernelGGL((stem_pool_kernel<PH, PW>), dim3((unsigned)grid), dim3(256), 0, stream, a, (unsigned)x_bytes,
+                       (unsigned)w_bytes);
+    FD_LAUNCH_CHECK();
+    return FD_OK;
+}
+
 int maxpool_3x3s2_split(const float* x, int batch, int h, int w, int c, const float* scale, const float* shift,
                         float* y32, void* ysplit, hipStream_t stream) {
     FD_REQUIRE(x && (y32 || ysplit) && c % 32 == 0, "maxpool (split): bad arguments");

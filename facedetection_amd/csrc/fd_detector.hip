@@ -466,13 +466,16 @@ static int run_graph_split(Plan& pl, const uint8_t* frames, int B, int H, int W,
     float* staged = pl.buf(NB_STAGED, (size_t)B * H * W * 4);
     if (!pl.dry) FD_TRY(stage_input_split(frames, B, H, W, d->norm, staged, pl.stream));
     const int h1 = d->s_conv0.s.out_h(H), w1 = d->s_conv0.s.out_w(W);
-    float* c0 = pl.buf(NB_CONV0, (size_t)B * h1 * w1 * FILTERS[0]);
-    if (!pl.dry) {
+    // Stem and max-pool run as one kernel.  When intermediate tensors are kept for inspection the
+    // two-kernel form is used instead, because only it materialises the convolution output.
+    const bool fused_stem = !keep && (size_t)B * H * W * 16 < (1ull << 31);
+    float* c0 = fused_stem ? nullptr : pl.buf(NB_CONV0, (size_t)B * h1 * w1 * FILTERS[0]);
+    if (!pl.dry && !fused_stem) {
         SplitConvOut o;
         o.y32 = c0;
         FD_TRY(split_conv_forward(d->s_conv0, staged, B, H, W, nullptr, o, pl.stream));
     }
-    pl.tap("conv0", c0, B, h1, w1, FILTERS[0]);
+    if (!fused_stem) pl.tap("conv0", c0, B, h1, w1, FILTERS[0]);
     int h = (h1 + 2 - 3) / 2 + 1, w = (w1 + 2 - 3) / 2 + 1;
     size_t xmax = (size_t)B * h * w * FILTERS[0];
     {
@@ -486,9 +489,14 @@ static int run_graph_split(Plan& pl, const uint8_t* frames, int B, int H, int W,
     float* xbuf[2] = {pl.buf(NB_XA, xmax), pl.buf(NB_XB, xmax)};
     float* abuf[2] = {pl.buf(NB_ACT_A, xmax), pl.buf(NB_ACT_B, xmax)};
     // max pool: float32 copy only for inspection; the first unit (projection shortcut) needs act only
-    if (!pl.dry)
-        FD_TRY(maxpool_3x3s2_split(c0, B, h1, w1, FILTERS[0], d->stage[0][0].bn1_scale, d->stage[0][0].bn1_shift,
-                                   keep ? xbuf[0] : nullptr, abuf[0], pl.stream));
+    if (!pl.dry) {
+        if (fused_stem)
+            FD_TRY(stem_pool_forward(d->s_conv0, staged, B, H, W, d->stage[0][0].bn1_scale, d->stage[0][0].bn1_shift,
+                                     nullptr, abuf[0], pl.stream));
+        else
+            FD_TRY(maxpool_3x3s2_split(c0, B, h1, w1, FILTERS[0], d->stage[0][0].bn1_scale,
+                                       d->stage[0][0].bn1_shift, keep ? xbuf[0] : nullptr, abuf[0], pl.stream));
+    }
     if (keep) pl.tap("pool0", xbuf[0], B, h, w, FILTERS[0]);
     int cur = 0;
     const float* xraw = nullptr;           // raw input of the next unit (NULL when it does not need one)
