@@ -1,12 +1,20 @@
 // Split-precision convolution: the implicit GEMM of fd_conv.hip with both operands carried as
-// two-way fp16 splits (fd_split.h) and the products formed on the f16 matrix cores
-// (v_mfma_f32_32x32x16_f16, three per 32x32x16 block: hi*hi + hi*lo + lo*hi, fp32 accumulate).
+// two-way fp16 splits (fd_split.h) and the products formed on the f16 matrix cores (three MFMAs
+// per block: hi*hi + hi*lo + lo*hi, fp32 accumulate).
 //
-// Because activations arrive already split (the producing kernel's epilogue wrote them that
-// way, with the consumer's BatchNorm+ReLU applied), the input gather is a pure 16-byte copy
-// global -> registers -> LDS for both operands: one 128-byte group [32 hi | 32 lo] of a pixel
-// is one staged row of a K-step.  The epilogue rescales by the weights' power-of-two factor,
-// adds bias / residual, and writes float32 and/or the split form for the next layer.
+// Kernels in this file, all on the same GEMM view (M = output pixels, N = output channels,
+// K = kh * kw * cin in steps of 32, one 128-byte row [32 hi | 32 lo] per pixel and K-step):
+//   conv_split_glds_kernel  - input already split: both operand tiles go global -> LDS by LDS-DMA;
+//                             v_mfma_f32_16x16x32_f16 blocks; 2..4 LDS stages.  The workhorse.
+//   conv_split_reg_kernel   - activations through registers into the same LDS image: float32
+//                             input with BatchNorm+ReLU+split on the way (REG_PRE), or the staged
+//                             4-channel image of the 7x7 stem (REG_STEM); weights by LDS-DMA.
+//   stem_pool_kernel        - the stem fused with the 3x3/2 max-pool (2-D tiles, patch in LDS).
+//   conv_split_kernel       - pointer-addressed, register-staged form with padded LDS rows and
+//                             32x32x16 blocks; taken only when a tensor exceeds the 2^31-byte
+//                             reach of the buffer-addressed kernels above.
+// Epilogues rescale by the weights' power-of-two factor, add bias / residual, and write float32
+// and/or the split form for the next layer (with that layer's BatchNorm+ReLU applied).
 #include "fd_conv_split.h"
 #include "fd_split.h"
 
