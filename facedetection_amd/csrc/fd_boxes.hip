@@ -484,6 +484,8 @@ struct AnchorTable {
 // Entry N-1-idx of the sort input holds anchor idx, so the stable sort breaks score
 // ties towards the higher anchor index.
 // ---------------------------------------------------------------------------------
+constexpr int DECODE_PER_BLOCK = 1024;
+
 template <typename T>
 __global__ __launch_bounds__(256) void proposal_decode_kernel(const float* __restrict__ cls,
                                                              const float* __restrict__ bbox, RpnLayout lay, int softmax,
@@ -494,9 +496,18 @@ __global__ __launch_bounds__(256) void proposal_decode_kernel(const float* __res
                                                              float* __restrict__ scores, uint32_t* __restrict__ keys,
                                                              uint32_t* __restrict__ vals, int32_t* __restrict__ counters,
                                                              int32_t* __restrict__ nan_flag) {
+    // A workgroup handles DECODE_PER_BLOCK consecutive anchors and adds its count of valid ones to
+    // the image's counter once: one same-address atomic per workgroup instead of one per wave
+    // (the atomics to a single address serialise; per wave they dominated this kernel's time).
+    __shared__ int s_valid;
+    if (threadIdx.x == 0) s_valid = 0;
+    __syncthreads();
     const int seg = blockIdx.y;
     const int N = H * W * A;
-    const int idx = blockIdx.x * 256 + threadIdx.x;
+    int nvalid = 0;
+#pragma unroll 1
+    for (int it = 0; it < DECODE_PER_BLOCK / 256; ++it) {
+    const int idx = blockIdx.x * DECODE_PER_BLOCK + it * 256 + threadIdx.x;
     bool valid = false;
     if (idx < N) {
         const int a = idx % A;
@@ -535,8 +546,11 @@ __global__ __launch_bounds__(256) void proposal_decode_kernel(const float* __res
         keys[p] = valid ? desc_key(score) : KEY_INVALID32;
         vals[p] = (uint32_t)idx;
     }
-    const uint64_t m = __ballot(valid);
-    if ((threadIdx.x & 63) == 0 && m) atomicAdd(&counters[seg * CNT_STRIDE + CNT_VALID], (int)__popcll(m));
+    nvalid += (int)__popcll(__ballot(valid));
+    }
+    if ((threadIdx.x & 63) == 0 && nvalid) atomicAdd(&s_valid, nvalid);
+    __syncthreads();
+    if (threadIdx.x == 0 && s_valid) atomicAdd(&counters[seg * CNT_STRIDE + CNT_VALID], s_valid);
 }
 
 template <typename T>
@@ -615,7 +629,7 @@ static int proposal_run_t(fd_ctx* ctx, const fd_proposal_cfg* cfg, const float* 
     {
         // per anchor: 2 scores + 4 deltas read, box + score + sort pair written
         ProfScope scope(stream, "proposal_decode", 0.0, (double)batch * N * (24.0 + 4.0 * sizeof(T) + 12.0));
-        hipLaunchKernelGGL(proposal_decode_kernel<T>, dim3(ceil_div(N, 256), batch), dim3(256), 0, stream, cls, bbox,
+        hipLaunchKernelGGL(proposal_decode_kernel<T>, dim3(ceil_div(N, DECODE_PER_BLOCK), batch), dim3(256), 0, stream, cls, bbox,
                            lay, softmax, anchors, A, H, W, cfg->feat_stride, im_info_dev, info_uniform[0],
                            info_uniform[1], info_uniform[2], cfg->min_size, boxes, scores, ka, va, counters, nan_flag);
         FD_LAUNCH_CHECK();
