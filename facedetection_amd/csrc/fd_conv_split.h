@@ -32,6 +32,13 @@ int split_conv_forward_f32(const SplitConvParams& p, const float* x32, const flo
                            int batch, int h, int w, const float* residual, const SplitConvOut& out,
                            hipStream_t stream);
 
+// conv2 (3x3/1, 64 -> 64, ReLU) and conv3 (1x1, 64 -> cout) of a residual unit in one kernel; the
+// tensor between them stays in LDS.  *taken is false (and nothing is launched) when the shapes are
+// not the ones this kernel is written for; the caller then runs the two convolutions separately.
+int conv_tail_fused_forward(const SplitConvParams& conv2, const SplitConvParams& conv3, const void* x_split, int batch,
+                            int h, int w, const float* residual, const SplitConvOut& out, hipStream_t stream,
+                            bool* taken);
+
 // float32 [rows][channels] -> split, optionally through relu(x * scale[c] + shift[c]).
 int to_split(const float* x, long long rows, int channels, const float* scale, const float* shift, void* y,
              hipStream_t stream);

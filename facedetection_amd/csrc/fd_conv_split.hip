@@ -319,6 +319,17 @@ struct SplitTile {
     static constexpr int AM = BM / 32, AN = BN / 32;  // 16x16 blocks per wave
 };
 
+// Geometry of the epilogue's row passes: after the transpose through LDS a lane owns 8
+// consecutive channels of one row per pass.
+template <int BM, int BN>
+struct SplitEpi {
+    static constexpr int WN = BN / 2;
+    static constexpr int L8 = WN / 8;           // lanes per row
+    static constexpr int RPP = 64 / L8;         // rows per pass
+    static constexpr int PASSES = 32 / RPP;     // passes per 32-row group
+    static constexpr int GROUPS = BM / 64;      // 32-row groups per wave
+};
+
 // all MFMAs of one K-step (32 k) of a wave's tile from the stage at `stage`
 template <int BM, int BN>
 __device__ __forceinline__ void split_mma_step(const char* stage, const int (&a_off)[2], const int (&b_off)[2],
@@ -347,9 +358,35 @@ __device__ __forceinline__ void split_mma_step(const char* stage, const int (&a_
 
 // Epilogue of a 16x16-block tile: transpose each wave's rows through its slice of LDS (32 rows
 // at a time); every lane then owns 8 consecutive channels of a row.
+// The residual values a lane adds in the epilogue, fetched ahead of time by kernels whose
+// per-workgroup chain of memory round trips would otherwise be exposed.
 template <int BM, int BN>
+__device__ __forceinline__ void split_residual_prefetch(const SplitKArgs& a, int tile_m, int tile_n, int wave, int lane,
+                                                        f32x4 (&res)[SplitEpi<BM, BN>::GROUPS][SplitEpi<BM, BN>::PASSES][2]) {
+    using E = SplitEpi<BM, BN>;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int erow = lane / E::L8, ecol = (lane % E::L8) * 8;
+    const int gcol = tile_n * BN + wn * E::WN + ecol;
+    const bool col_ok = gcol < a.Cout;
+#pragma unroll
+    for (int mi = 0; mi < E::GROUPS; ++mi)
+#pragma unroll
+        for (int ps = 0; ps < E::PASSES; ++ps) {
+            const int row = tile_m * BM + wm * (BM / 2) + mi * 32 + ps * E::RPP + erow;
+            res[mi][ps][0] = f32x4{0.f, 0.f, 0.f, 0.f};
+            res[mi][ps][1] = res[mi][ps][0];
+            if (a.res && row < a.M && col_ok) {
+                const float* rp = a.res + (size_t)row * a.Cout + gcol;
+                res[mi][ps][0] = *reinterpret_cast<const f32x4*>(rp);
+                res[mi][ps][1] = *reinterpret_cast<const f32x4*>(rp + 4);
+            }
+        }
+}
+
+template <int BM, int BN, bool PREFETCHED = false>
 __device__ __forceinline__ void split_epilogue16(const SplitKArgs& a, float* smem, int tile_m, int tile_n, int wave,
-                                                 int lane, f32x4 (&acc)[BM / 32][BN / 32]) {
+                                                 int lane, f32x4 (&acc)[BM / 32][BN / 32],
+                                                 f32x4 (*pres)[SplitEpi<BM, BN>::PASSES][2] = nullptr) {
     using T = SplitTile<BM, BN>;
     constexpr int WN = T::WN, LDC = T::LDC, AN = T::AN;
     constexpr int L8 = WN / 8;
@@ -378,7 +415,10 @@ __device__ __forceinline__ void split_epilogue16(const SplitKArgs& a, float* sme
     for (int mi = 0; mi < BM / 64; ++mi) {
         const int grow0 = tile_m * BM + wm * (BM / 2) + mi * 32;
         f32x4 res0[PASSES], res1[PASSES];
-        if (a.res) {
+        if (PREFETCHED) {
+#pragma unroll
+            for (int ps = 0; ps < PASSES; ++ps) { res0[ps] = pres[mi][ps][0]; res1[ps] = pres[mi][ps][1]; }
+        } else if (a.res) {
 #pragma unroll
             for (int ps = 0; ps < PASSES; ++ps) {
                 const int row = grow0 + ps * RPP + erow;
@@ -871,6 +911,268 @@ static int split_conv_dispatch(const SplitConvParams& p, const void* x_split, co
     if (s.cout > 64 && t128 >= 384) return launch_split<128, 128, false>(a, stream);
     if (t12864 >= 384) return launch_split<128, 64, false>(a, stream);
     return launch_split<64, 64, false>(a, stream);
+}
+
+// ---------------------------------------------------------------------------------
+// Bottleneck tail in one kernel: the 3x3 convolution of a residual unit and the 1x1 convolution
+// that follows it, for units whose middle width is 64 channels (stage 1).  A workgroup computes a
+// 128 x 64 tile of the 3x3 output -- all 64 channels of 128 pixels, i.e. the complete K of the
+// 1x1 -- keeps it in LDS as the split A operand (bias + ReLU applied), and runs the 1x1 against
+// it in four chunks of 64 output channels with the usual epilogue (residual add, float32 and/or
+// split output).  The intermediate tensor never goes to HBM (530 MB per 8 frames at 1080p and
+// unit), and the compute-heavy and the traffic-heavy phase of co-resident workgroups overlap.
+// LDS: [epilogue staging 18 KB | A operand 32 KB | weight chunk 16 KB]; the K loop of the 3x3
+// uses the first 48 KB as its two pipeline stages before that.
+template <int BM, int MID>
+__global__ __launch_bounds__(256, 2) void conv_tail_fused_kernel(SplitKArgs a, SplitKArgs c, unsigned x_bytes,
+                                                                unsigned w_bytes, unsigned w3_bytes) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    static_assert(BM == 128 && MID == 64, "written for 128-pixel tiles of a 64-channel middle layer");
+    constexpr int BN = MID;
+    using T = SplitTile<BM, BN>;
+    using E = SplitEpi<BM, BN>;
+    constexpr int GA = BM / 32, GB = BN / 32;
+    constexpr int STAGE = T::STAGE;                       // dwords
+    constexpr int CS_BYTES = 20 * 1024;                   // epilogue staging (18 KB used)
+    constexpr int AIMG_BYTES = (MID / 32) * BM * 128;     // the 1x1's A operand: MID/32 K-steps of BM rows
+    constexpr int WCH_BYTES = (MID / 32) * 64 * 128;      // one chunk of 64 output channels of the 1x1's weights
+    constexpr int SMEM_BYTES = CS_BYTES + AIMG_BYTES + WCH_BYTES;
+    static_assert(2 * STAGE * 4 <= SMEM_BYTES && T::EPI * 4 <= CS_BYTES && SMEM_BYTES <= 80 * 1024, "LDS plan");
+    __shared__ __attribute__((aligned(16))) float smem[SMEM_BYTES / 4];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    int tile_m;
+    {
+        const int nwg = gridDim.x, bid = blockIdx.x;
+        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+        tile_m = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    }
+
+    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, w_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t w3r = __builtin_amdgcn_make_buffer_rsrc((void*)c.w, 0, w3_bytes, 0x00020000);
+    constexpr unsigned OOB = 0x80000000u;
+
+    // ---- phase 1: the 3x3 convolution, as in conv_split_glds_kernel<128, 64, 2> ----
+    const int lrow = lane >> 3, lpos = lane & 7;
+    int hi0[GA], wi0[GA];
+    unsigned abase[GA];
+    bool mval[GA];
+#pragma unroll
+    for (int i = 0; i < GA; ++i) {
+        const int row = (wave + 4 * i) * 8 + lrow;
+        const int chunk = lpos ^ ((row >> 1) & 7);
+        const int m = tile_m * BM + row;
+        mval[i] = m < a.M;
+        const int mm = mval[i] ? m : 0;
+        const int hw = a.Ho * a.Wo;
+        const int img = mm / hw;
+        const int rem = mm - img * hw;
+        const int ho = rem / a.Wo;
+        const int wo = rem - ho * a.Wo;
+        hi0[i] = ho * a.stride - a.pad;
+        wi0[i] = wo * a.stride - a.pad;
+        abase[i] = (unsigned)(((img * a.H + hi0[i]) * a.W + wi0[i]) * a.Cin * 4 + chunk * 16);
+    }
+    unsigned bvo[GB];
+#pragma unroll
+    for (int i = 0; i < GB; ++i) {
+        const int row = (wave + 4 * i) * 8 + lrow;
+        bvo[i] = (unsigned)(row * a.K * 4 + (lpos ^ ((row >> 1) & 7)) * 16);
+    }
+    int kh = 0, kw = 0, coff = 0;
+    const int nk = a.K / SBK;
+    unsigned avo[GA];
+#define FD_TAP()                                                                                  \
+    do {                                                                                          \
+        const unsigned toff_ = (unsigned)((kh * a.W + kw) * a.Cin * 4);                           \
+        _Pragma("unroll") for (int i = 0; i < GA; ++i) {                                          \
+            const int hi_ = hi0[i] + kh, wi_ = wi0[i] + kw;                                       \
+            const bool ok_ = mval[i] && (unsigned)hi_ < (unsigned)a.H && (unsigned)wi_ < (unsigned)a.W; \
+            avo[i] = ok_ ? abase[i] + toff_ : OOB;                                                \
+        }                                                                                         \
+    } while (0)
+#define FD_ISSUE(KT, STG)                                                                         \
+    do {                                                                                          \
+        float* sa_ = smem + (STG) * STAGE;                                                        \
+        _Pragma("unroll") for (int i = 0; i < GA; ++i)                                            \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(                                             \
+                xr, (__attribute__((address_space(3))) void*)(sa_ + (wave + 4 * i) * 256), 16, avo[i], coff * 4, 0, 0); \
+        _Pragma("unroll") for (int i = 0; i < GB; ++i)                                            \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(                                             \
+                wr, (__attribute__((address_space(3))) void*)(sa_ + BM * 32 + (wave + 4 * i) * 256), 16, \
+                bvo[i], (KT) * 128, 0, 0);                                                        \
+        coff += SBK;                                                                              \
+        if (coff >= a.Cin) {                                                                      \
+            coff = 0;                                                                             \
+            if (++kw == a.KW) { kw = 0; ++kh; }                                                   \
+            FD_TAP();                                                                             \
+        }                                                                                         \
+    } while (0)
+
+    f32x4 acc[T::AM][T::AN];
+#pragma unroll
+    for (int mi = 0; mi < T::AM; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < T::AN; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int frow = lane & 15, fh = lane >> 4;
+    const int sw = (frow >> 1) & 7;
+    const char* sbase = reinterpret_cast<const char*>(smem);
+    int a_off[2], b_off[2];
+#pragma unroll
+    for (int part = 0; part < 2; ++part) {
+        const int pos = ((part * 4 + fh) ^ sw) * 16;
+        a_off[part] = (wm * (BM / 2) + frow) * 128 + pos;
+        b_off[part] = (BM + wn * (BN / 2) + frow) * 128 + pos;
+    }
+#define FD_STEP(CUR, KT)                                                                          \
+    do {                                                                                          \
+        if ((KT) + 1 < nk) FD_ISSUE((KT) + 1, (CUR) ^ 1);                                         \
+        split_mma_step<BM, BN>(sbase + (CUR) * STAGE * 4, a_off, b_off, acc);                     \
+        wait_vmcnt<0>();                                                                          \
+        __syncthreads();                                                                          \
+    } while (0)
+    FD_TAP();
+    FD_ISSUE(0, 0);
+    wait_vmcnt<0>();
+    __syncthreads();
+    for (int kt = 0; kt < nk; kt += 2) {
+        FD_STEP(0, kt);
+        if (kt + 1 < nk) FD_STEP(1, kt + 1);
+    }
+#undef FD_STEP
+#undef FD_ISSUE
+#undef FD_TAP
+
+    // ---- phase 2: bias + ReLU + split of the 128 x 64 tile into the 1x1's A operand in LDS ----
+    // (transposed through the staging area like the epilogue, 32 rows at a time; a wave's 32
+    // columns are exactly one K-step of the 1x1: K-step index = wn)
+    char* aimg = reinterpret_cast<char*>(smem) + CS_BYTES;
+    {
+        constexpr int LDC = T::LDC;
+        float* Cs = smem + wave * (32 * LDC);
+        const int erow = lane / E::L8, ecol = (lane % E::L8) * 8;
+        float bias_v[T::AN];
+#pragma unroll
+        for (int ni = 0; ni < T::AN; ++ni) bias_v[ni] = a.bias ? a.bias[wn * 32 + ni * 16 + (lane & 15)] : 0.f;
+#pragma unroll
+        for (int mi = 0; mi < E::GROUPS; ++mi) {
+            if (mi > 0) __syncthreads();
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+                for (int ni = 0; ni < T::AN; ++ni)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        Cs[(mb * 16 + (lane >> 4) * 4 + r) * LDC + ni * 16 + (lane & 15)] =
+                            fmaxf(acc[mi * 2 + mb][ni][r] * a.w_inv_scale + bias_v[ni], 0.f);
+            __syncthreads();
+#pragma unroll
+            for (int ps = 0; ps < E::PASSES; ++ps) {
+                const int lrow2 = ps * E::RPP + erow;
+                const int row = wm * (BM / 2) + mi * 32 + lrow2;
+                const f32x4 v0 = *reinterpret_cast<const f32x4*>(&Cs[lrow2 * LDC + ecol]);
+                const f32x4 v1 = *reinterpret_cast<const f32x4*>(&Cs[lrow2 * LDC + ecol + 4]);
+                f16x8 hi, lo;
+                split8(v0, v1, hi, lo);
+                char* kstep = aimg + wn * (BM * 128);
+                const int off = row * 128 + (((ecol >> 3) ^ ((row >> 1) & 7)) * 16);
+                *reinterpret_cast<f16x8*>(kstep + off) = hi;
+                *reinterpret_cast<f16x8*>(kstep + (off ^ 64)) = lo;      // lo chunk = hi chunk + 4
+            }
+        }
+    }
+
+    // ---- phase 3: the 1x1 convolution, 64 output channels at a time ----
+    float* wch = smem + (CS_BYTES + AIMG_BYTES) / 4;
+    int a3_off[MID / 32][2], b3_off[MID / 32][2];
+#pragma unroll
+    for (int kk = 0; kk < MID / 32; ++kk)
+#pragma unroll
+        for (int part = 0; part < 2; ++part) {
+            const int pos = ((part * 4 + fh) ^ sw) * 16;
+            a3_off[kk][part] = CS_BYTES + kk * (BM * 128) + (wm * (BM / 2) + frow) * 128 + pos;
+            b3_off[kk][part] = CS_BYTES + AIMG_BYTES + kk * (64 * 128) + (wn * 32 + frow) * 128 + pos;
+        }
+    // Software pipeline over the chunks: the weights and the residual values of chunk ch + 1 are
+    // requested before the epilogue of chunk ch runs, so neither round trip is exposed.  vmcnt
+    // counts in order: the weight loads of a chunk are always older than its residual loads.
+    constexpr int RL = E::GROUPS * E::PASSES * 2;        // residual loads per chunk and lane
+#define FD_WEIGHTS(CH)                                                                            \
+    do {                                                                                          \
+        _Pragma("unroll") for (int kk = 0; kk < MID / 32; ++kk)                                   \
+            _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                       \
+                const int row = (wave + 4 * i) * 8 + lrow;                                        \
+                const unsigned vo = (unsigned)((((CH) * 64 + row) * MID + kk * 32) * 4 + (lpos ^ ((row >> 1) & 7)) * 16); \
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(                                         \
+                    w3r, (__attribute__((address_space(3))) void*)(wch + kk * (64 * 32) + (wave + 4 * i) * 256), 16, vo, \
+                    0, 0, 0);                                                                     \
+            }                                                                                     \
+    } while (0)
+#define FD_CHUNK(CH, RCUR, RNEXT)                                                                 \
+    do {                                                                                          \
+        wait_vmcnt<RL>();              /* weights of this chunk landed; its residual may fly */   \
+        __syncthreads();               /* ... for every wave; first chunk: A operand complete */  \
+        f32x4 acc3[T::AM][T::AN];                                                                 \
+        _Pragma("unroll") for (int mi = 0; mi < T::AM; ++mi)                                      \
+            _Pragma("unroll") for (int ni = 0; ni < T::AN; ++ni) acc3[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f}; \
+        _Pragma("unroll") for (int kk = 0; kk < MID / 32; ++kk)                                   \
+            split_mma_step<BM, BN>(sbase, a3_off[kk], b3_off[kk], acc3);                          \
+        __syncthreads();               /* every wave is done reading the weight chunk */          \
+        if ((CH) + 1 < nch) {                                                                     \
+            FD_WEIGHTS((CH) + 1);                                                                 \
+            split_residual_prefetch<BM, BN>(c, tile_m, (CH) + 1, wave, lane, RNEXT);              \
+            __builtin_amdgcn_sched_barrier(0);                                                    \
+        }                                                                                         \
+        split_epilogue16<BM, BN, true>(c, smem, tile_m, (CH), wave, lane, acc3, RCUR);            \
+    } while (0)
+
+    const int nch = c.Cout / 64;
+    f32x4 resA[E::GROUPS][E::PASSES][2], resB[E::GROUPS][E::PASSES][2];
+    FD_WEIGHTS(0);
+    split_residual_prefetch<BM, BN>(c, tile_m, 0, wave, lane, resA);
+    __builtin_amdgcn_sched_barrier(0);
+    for (int ch = 0; ch < nch; ch += 2) {
+        FD_CHUNK(ch, resA, resB);
+        if (ch + 1 < nch) FD_CHUNK(ch + 1, resB, resA);
+    }
+#undef FD_CHUNK
+#undef FD_WEIGHTS
+#endif
+}
+
+int conv_tail_fused_forward(const SplitConvParams& p2, const SplitConvParams& p3, const void* x_split, int batch, int h,
+                            int w, const float* residual, const SplitConvOut& out, hipStream_t stream, bool* taken) {
+    *taken = false;
+    const ConvShape &s2 = p2.s, &s3 = p3.s;
+    if (!(s2.cin == 64 && s2.cout == 64 && s2.kh == 3 && s2.kw == 3 && s2.kwp == 3 && s2.stride == 1 && s2.pad == 1 &&
+          p2.relu && s3.cin == 64 && s3.kh == 1 && s3.kw == 1 && s3.stride == 1 && s3.pad == 0 && s3.cout % 64 == 0))
+        return FD_OK;
+    const long long m_ll = (long long)batch * h * w;
+    const size_t x_bytes = (size_t)m_ll * 64 * 4, w_bytes = s2.packed_floats() * 4, w3_bytes = s3.packed_floats() * 4;
+    if (x_bytes >= (1ull << 31) || (size_t)m_ll * s3.cout * 4 >= (1ull << 33) || m_ll >= (1ll << 29)) return FD_OK;
+    FD_REQUIRE(x_split && p2.w && p3.w && (out.y32 || out.ysplit), "fused tail: NULL tensor");
+    SplitKArgs a, c;
+    a.x = static_cast<const uint8_t*>(x_split); a.w = static_cast<const uint8_t*>(p2.w);
+    a.bias = p2.bias; a.res = nullptr; a.y32 = nullptr; a.ysplit = nullptr; a.post_scale = a.post_shift = nullptr;
+    a.pre_scale = a.pre_shift = nullptr; a.w_inv_scale = p2.w_inv_scale;
+    a.H = h; a.W = w; a.Cin = 64; a.Ho = h; a.Wo = w; a.Cout = 64; a.KW = 3; a.stride = 1; a.pad = 1; a.K = s2.k();
+    a.M = (int)m_ll; a.relu = 1; a.tiles_n = 1;
+    c = a;
+    c.x = nullptr; c.w = static_cast<const uint8_t*>(p3.w); c.bias = p3.bias; c.res = residual; c.y32 = out.y32;
+    c.ysplit = static_cast<uint8_t*>(out.ysplit); c.post_scale = out.post_scale; c.post_shift = out.post_shift;
+    c.w_inv_scale = p3.w_inv_scale; c.Cin = 64; c.Cout = s3.cout; c.KW = 1; c.pad = 0; c.K = 64; c.relu = p3.relu;
+    c.tiles_n = s3.cout / 64;
+    const int tiles_m = ceil_div(a.M, 128);
+    ProfScope scope(stream, "conv_tail_fused", 2.0 * a.M * 64.0 * (double)a.K + 2.0 * a.M * (double)s3.cout * 64.0,
+                    4.0 * 64.0 * a.M + 4.0 * 64.0 * (a.K + s3.cout) +
+                        4.0 * a.M * s3.cout * ((c.res ? 1.0 : 0.0) + (c.y32 ? 1.0 : 0.0) + (c.ysplit ? 1.0 : 0.0)));
+    hipLaunchKernelGGL((conv_tail_fused_kernel<128, 64>), dim3(tiles_m), dim3(256), 0, stream, a, c, (unsigned)x_bytes,
+                       (unsigned)w_bytes, (unsigned)w3_bytes);
+    FD_LAUNCH_CHECK();
+    *taken = true;
+    return FD_OK;
 }
 
 int split_conv_forward(const SplitConvParams& p, const void* x_split, int batch, int h, int w, const float* residual,

@@ -449,8 +449,12 @@ static int run_unit_split(Plan& pl, const Unit& u, const char* name, const void*
             FD_TRY(split_conv_forward_f32(u.s_conv1, xraw, u.bn1_scale, u.bn1_shift, n, h, w, nullptr, o1,
                                           pl.stream));
         }
-        FD_TRY(split_conv_forward(u.s_conv2, t1, n, h, w, nullptr, o2, pl.stream));
-        FD_TRY(split_conv_forward(u.s_conv3, t2, n, ho, wo, res, o3, pl.stream));
+        bool fused = false;
+        if (!pl.d->keep_taps) FD_TRY(conv_tail_fused_forward(u.s_conv2, u.s_conv3, t1, n, h, w, res, o3, pl.stream, &fused));
+        if (!fused) {
+            FD_TRY(split_conv_forward(u.s_conv2, t1, n, h, w, nullptr, o2, pl.stream));
+            FD_TRY(split_conv_forward(u.s_conv3, t2, n, ho, wo, res, o3, pl.stream));
+        }
     }
     if (y32) pl.tap(name, y32, n, ho, wo, cout);
     *ho_out = ho;
