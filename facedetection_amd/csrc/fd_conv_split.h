@@ -17,6 +17,8 @@ struct SplitConvOut {
     void* ysplit = nullptr;            // split output or NULL
     const float* post_scale = nullptr; // split output = split(relu(y * post_scale + post_shift)); NULL: split(y)
     const float* post_shift = nullptr;
+    float* splitk_ws = nullptr;        // optional workspace for split-K partial sums (small grids only)
+    size_t splitk_ws_floats = 0;
 };
 
 int pack_conv_weights_split(const float* w_oihw, int cin_w, const ConvShape& s, const float* out_scale, float wscale,

@@ -40,6 +40,10 @@ struct SplitKArgs {
     const float* pre_shift;
     float w_inv_scale;
     int H, W, Cin, Ho, Wo, Cout, KW, stride, pad, K, M, relu, tiles_n;
+    // split-K (small grids): workgroup ks of a tile sums K-steps [ks * kchunk, (ks + 1) * kchunk) and
+    // writes its scaled partial sums to partial[ks][M][Cout]; split_k_finish_kernel adds them up
+    int ksplit, kchunk;
+    float* partial;
 };
 
 constexpr int SBK = 32;      // k per K-step
@@ -512,7 +516,8 @@ __global__ __launch_bounds__(256, 2) void conv_split_glds_kernel(SplitKArgs a, u
         const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
         wgid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
     }
-    const int tile_n = wgid % a.tiles_n, tile_m = wgid / a.tiles_n;
+    const int ks = wgid % a.ksplit;
+    const int tile_n = (wgid / a.ksplit) % a.tiles_n, tile_m = wgid / (a.ksplit * a.tiles_n);
 
     const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, x_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, w_bytes, 0x00020000);
@@ -546,8 +551,16 @@ __global__ __launch_bounds__(256, 2) void conv_split_glds_kernel(SplitKArgs a, u
         const int chunk = lpos ^ ((row >> 1) & 7);
         bvo[i] = (unsigned)((tile_n * BN + row) * a.K * 4 + chunk * 16);
     }
-    int kh = 0, kw = 0, coff = 0;
-    const int nk = a.K / SBK;
+    // this workgroup's K-steps: kb .. kb + nk - 1 (everything unless the launch splits K)
+    const int kb = ks * a.kchunk;
+    const int nk = min(a.K / SBK, kb + a.kchunk) - kb;
+    int kh, kw, coff;
+    {
+        const int tap = (kb * SBK) / a.Cin;
+        coff = kb * SBK - tap * a.Cin;
+        kh = tap / a.KW;
+        kw = tap - kh * a.KW;
+    }
 
     // Per-lane offsets of the activation rows change only with the filter tap (validity of the
     // tap for the row's window); the channel position inside the tap and the K position in the
@@ -572,7 +585,7 @@ __global__ __launch_bounds__(256, 2) void conv_split_glds_kernel(SplitKArgs a, u
         _Pragma("unroll") for (int i = 0; i < GB; ++i)                                            \
             __builtin_amdgcn_raw_ptr_buffer_load_lds(                                             \
                 wr, (__attribute__((address_space(3))) void*)(sa_ + BM * 32 + (wave + 4 * i) * 256), 16, \
-                bvo[i], (KT) * 128, 0, 0);                                                        \
+                bvo[i], (kb + (KT)) * 128, 0, 0);                                                        \
         coff += SBK;                                                                              \
         if (coff >= a.Cin) {                                                                      \
             coff = 0;                                                                             \
@@ -638,7 +651,14 @@ __global__ __launch_bounds__(256, 2) void conv_split_glds_kernel(SplitKArgs a, u
 #undef FD_WAIT
 #undef FD_ISSUE
 #undef FD_TAP
-    split_epilogue16<BM, BN>(a, smem, tile_m, tile_n, wave, lane, acc);
+    if (a.ksplit > 1) {
+        SplitKArgs e = a;            // raw scaled partial sums; bias, ReLU, residual and split follow in the finish kernel
+        e.y32 = a.partial + (size_t)ks * a.M * a.Cout;
+        e.ysplit = nullptr; e.bias = nullptr; e.res = nullptr; e.relu = 0;
+        split_epilogue16<BM, BN>(e, smem, tile_m, tile_n, wave, lane, acc);
+    } else {
+        split_epilogue16<BM, BN>(a, smem, tile_m, tile_n, wave, lane, acc);
+    }
 #endif
 }
 
@@ -651,8 +671,8 @@ static int launch_split_glds(const SplitKArgs& a, size_t x_bytes, size_t w_bytes
     SplitKArgs k = a;
     const int tiles_m = ceil_div(a.M, BM);
     k.tiles_n = ceil_div(a.Cout, BN);
-    hipLaunchKernelGGL((conv_split_glds_kernel<BM, BN, NS>), dim3(tiles_m * k.tiles_n), dim3(256), 0, stream, k,
-                       (unsigned)x_bytes, (unsigned)w_bytes);
+    hipLaunchKernelGGL((conv_split_glds_kernel<BM, BN, NS>), dim3(tiles_m * k.tiles_n * k.ksplit), dim3(256), 0, stream,
+                       k, (unsigned)x_bytes, (unsigned)w_bytes);
     FD_LAUNCH_CHECK();
     return FD_OK;
 }
@@ -674,7 +694,8 @@ __global__ __launch_bounds__(256, 2) void conv_split_reg_kernel(SplitKArgs a, un
         const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
         wgid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
     }
-    const int tile_n = wgid % a.tiles_n, tile_m = wgid / a.tiles_n;
+    const int ks = wgid % a.ksplit;
+    const int tile_n = (wgid / a.ksplit) % a.tiles_n, tile_m = wgid / (a.ksplit * a.tiles_n);
 
     const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, x_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, w_bytes, 0x00020000);
@@ -710,8 +731,17 @@ __global__ __launch_bounds__(256, 2) void conv_split_reg_kernel(SplitKArgs a, un
         const int chunk = lpos ^ ((row >> 1) & 7);
         bvo[i] = (unsigned)((tile_n * BN + row) * a.K * 4 + chunk * 16);
     }
-    int kh = 0, kw = 0, coff = 0;
-    const int nk = a.K / SBK;
+    const int kb = ks * a.kchunk;                // first K-step of this workgroup (0 unless K is split)
+    const int nk = min(a.K / SBK, kb + a.kchunk) - kb;
+    int kh, kw, coff;
+    if (MODE == REG_STEM) {
+        kh = kb; kw = 0; coff = 0;
+    } else {
+        const int tap = (kb * SBK) / a.Cin;
+        coff = kb * SBK - tap * a.Cin;
+        kh = tap / a.KW;
+        kw = tap - kh * a.KW;
+    }
     unsigned avo[RA], okbits = 0;
     f32x4 ra[RA];
     f32x4 psc = {1.f, 1.f, 1.f, 1.f}, psh = {0.f, 0.f, 0.f, 0.f};
@@ -742,7 +772,7 @@ __global__ __launch_bounds__(256, 2) void conv_split_reg_kernel(SplitKArgs a, un
         _Pragma("unroll") for (int i = 0; i < GB; ++i)                                            \
             __builtin_amdgcn_raw_ptr_buffer_load_lds(                                             \
                 wr, (__attribute__((address_space(3))) void*)(sa_ + BM * 32 + (wave + 4 * i) * 256), 16, \
-                bvo[i], (KT) * 128, 0, 0);                                                        \
+                bvo[i], (kb + (KT)) * 128, 0, 0);                                                        \
         if (MODE == REG_STEM) {                                                                   \
             ++kh;                                                                                 \
             FD_TAP();                                                                             \
@@ -821,7 +851,14 @@ __global__ __launch_bounds__(256, 2) void conv_split_reg_kernel(SplitKArgs a, un
 #undef FD_LSTORE
 #undef FD_GLOAD
 #undef FD_TAP
-    split_epilogue16<BM, BN>(a, smem, tile_m, tile_n, wave, lane, acc);
+    if (a.ksplit > 1) {
+        SplitKArgs e = a;
+        e.y32 = a.partial + (size_t)ks * a.M * a.Cout;
+        e.ysplit = nullptr; e.bias = nullptr; e.res = nullptr; e.relu = 0;
+        split_epilogue16<BM, BN>(e, smem, tile_m, tile_n, wave, lane, acc);
+    } else {
+        split_epilogue16<BM, BN>(a, smem, tile_m, tile_n, wave, lane, acc);
+    }
 #endif
 }
 
@@ -837,8 +874,8 @@ static int launch_split_reg(const SplitKArgs& a, size_t x_bytes, size_t w_bytes,
     SplitKArgs k = a;
     const int tiles_m = ceil_div(a.M, BM);
     k.tiles_n = ceil_div(a.Cout, BN);
-    hipLaunchKernelGGL((conv_split_reg_kernel<BM, BN, MODE>), dim3(tiles_m * k.tiles_n), dim3(256), 0, stream, k,
-                       (unsigned)x_bytes, (unsigned)w_bytes);
+    hipLaunchKernelGGL((conv_split_reg_kernel<BM, BN, MODE>), dim3(tiles_m * k.tiles_n * k.ksplit), dim3(256), 0, stream,
+                       k, (unsigned)x_bytes, (unsigned)w_bytes);
     FD_LAUNCH_CHECK();
     return FD_OK;
 }
@@ -856,6 +893,79 @@ static int launch_split(const SplitKArgs& a, hipStream_t stream) {
     const int tiles_m = ceil_div(a.M, BM);
     k.tiles_n = ceil_div(a.Cout, BN);
     hipLaunchKernelGGL((conv_split_kernel<BM, BN, STEM, PRE>), dim3(tiles_m * k.tiles_n), dim3(256), 0, stream, k);
+    FD_LAUNCH_CHECK();
+    return FD_OK;
+}
+
+// Sum of the split-K partial tensors, then the part of the epilogue the partial launches left out:
+// bias, ReLU, residual, float32 and/or split output.  One thread per 8 channels of a row.
+__global__ __launch_bounds__(256) void split_k_finish_kernel(SplitKArgs a) {
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    const int c8n = a.Cout / 8;
+    if (t >= (long long)a.M * c8n) return;
+    const int col = (int)(t % c8n) * 8;
+    const long long row = t / c8n;
+    const size_t off = (size_t)row * a.Cout + col, plane = (size_t)a.M * a.Cout;
+    f32x4 v0 = {0.f, 0.f, 0.f, 0.f}, v1 = v0;
+    for (int s = 0; s < a.ksplit; ++s) {
+        v0 += *reinterpret_cast<const f32x4*>(a.partial + s * plane + off);
+        v1 += *reinterpret_cast<const f32x4*>(a.partial + s * plane + off + 4);
+    }
+    if (a.bias) {
+        v0 += *reinterpret_cast<const f32x4*>(a.bias + col);
+        v1 += *reinterpret_cast<const f32x4*>(a.bias + col + 4);
+    }
+    if (a.relu) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { v0[j] = fmaxf(v0[j], 0.f); v1[j] = fmaxf(v1[j], 0.f); }
+    }
+    if (a.res) {
+        v0 += *reinterpret_cast<const f32x4*>(a.res + off);
+        v1 += *reinterpret_cast<const f32x4*>(a.res + off + 4);
+    }
+    if (a.y32) {
+        *reinterpret_cast<f32x4*>(a.y32 + off) = v0;
+        *reinterpret_cast<f32x4*>(a.y32 + off + 4) = v1;
+    }
+    if (a.ysplit) {
+        if (a.post_scale) {
+            const f32x4 s0 = *reinterpret_cast<const f32x4*>(a.post_scale + col);
+            const f32x4 s1 = *reinterpret_cast<const f32x4*>(a.post_scale + col + 4);
+            const f32x4 t0 = *reinterpret_cast<const f32x4*>(a.post_shift + col);
+            const f32x4 t1 = *reinterpret_cast<const f32x4*>(a.post_shift + col + 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                v0[j] = fmaxf(v0[j] * s0[j] + t0[j], 0.f);
+                v1[j] = fmaxf(v1[j] * s1[j] + t1[j], 0.f);
+            }
+        }
+        f16x8 hi, lo;
+        split8(v0, v1, hi, lo);
+        uint8_t* sp = a.ysplit + (size_t)row * a.Cout * 4 + split_offset(col);
+        *reinterpret_cast<f16x8*>(sp) = hi;
+        *reinterpret_cast<f16x8*>(sp + 64) = lo;
+    }
+}
+
+// The convolutions of the ROI head see 7x7 or 4x4 pixels per roi: a few hundred GEMM rows, so a
+// 64x64-tile launch leaves most CUs idle while each workgroup runs one long serial K loop.  There
+// K is cut into ranges summed by a second kernel.  The number of ranges is a function of K alone
+// (as long as the partial sums fit the workspace), never of the batch size, so a frame's result
+// does not depend on how many frames share the launch.
+static int choose_split_k(int pixels_per_image, int nk, long long out_floats, size_t ws_floats, int* kchunk) {
+    *kchunk = nk;
+    if (pixels_per_image > 49 || nk < 16 || ws_floats == 0) return 1;
+    int want = nk / 8;
+    if (want > 8) want = 8;
+    if ((size_t)want * (size_t)out_floats > ws_floats) return 1;
+    *kchunk = ceil_div(nk, want);
+    return ceil_div(nk, *kchunk);
+}
+
+static int split_k_finish(const SplitKArgs& a, hipStream_t stream) {
+    const long long items = (long long)a.M * (a.Cout / 8);
+    ProfScope scope(stream, "split_k_finish", 0.0, 4.0 * a.M * a.Cout * (a.ksplit + 2.0));
+    hipLaunchKernelGGL(split_k_finish_kernel, dim3((unsigned)ceil_div(items, 256)), dim3(256), 0, stream, a);
     FD_LAUNCH_CHECK();
     return FD_OK;
 }
@@ -883,6 +993,7 @@ static int split_conv_dispatch(const SplitConvParams& p, const void* x_split, co
     a.pre_scale = pre_scale; a.pre_shift = pre_shift;
     a.H = h; a.W = w; a.Cin = s.cin; a.Ho = ho; a.Wo = wo; a.Cout = s.cout; a.KW = s.kwp;
     a.stride = s.stride; a.pad = s.pad; a.K = s.k(); a.M = (int)m_ll; a.relu = p.relu; a.tiles_n = 0;
+    a.ksplit = 1; a.kchunk = a.K / SBK; a.partial = nullptr;
     FD_REQUIRE(!(stem && pre_scale), "split conv: the stem takes the staged image only");
     // the buffer-addressed kernels use 32-bit byte offsets below 2^31 into both tensors
     const size_t x_bytes = (size_t)batch * h * w * s.cin * 4, w_bytes = s.packed_floats() * 4;
@@ -893,6 +1004,16 @@ static int split_conv_dispatch(const SplitConvParams& p, const void* x_split, co
     }
     const long long t128 = (long long)ceil_div(a.M, 128) * ceil_div(s.cout, 128);
     const long long t12864 = (long long)ceil_div(a.M, 128) * ceil_div(s.cout, 64);
+    if (small) {
+        // ROI-head layers: split K whenever the workspace allows, whatever the batch size
+        a.ksplit = choose_split_k(ho * wo, a.K / SBK, (long long)a.M * s.cout, out.splitk_ws_floats, &a.kchunk);
+        if (a.ksplit > 1) {
+            a.partial = out.splitk_ws;
+            if (pre_scale) FD_TRY((launch_split_reg<64, 64, REG_PRE>(a, x_bytes, w_bytes, stream)));
+            else FD_TRY((launch_split_glds<64, 64, 4>(a, x_bytes, w_bytes, stream)));
+            return split_k_finish(a, stream);
+        }
+    }
     if (pre_scale) {
         if (small) {
             if (s.cout > 64 && t128 >= 384) return launch_split_reg<128, 128, REG_PRE>(a, x_bytes, w_bytes, stream);
@@ -1159,6 +1280,7 @@ int conv_tail_fused_forward(const SplitConvParams& p2, const SplitConvParams& p3
     a.pre_scale = a.pre_shift = nullptr; a.w_inv_scale = p2.w_inv_scale;
     a.H = h; a.W = w; a.Cin = 64; a.Ho = h; a.Wo = w; a.Cout = 64; a.KW = 3; a.stride = 1; a.pad = 1; a.K = s2.k();
     a.M = (int)m_ll; a.relu = 1; a.tiles_n = 1;
+    a.ksplit = 1; a.kchunk = a.K / SBK; a.partial = nullptr;
     c = a;
     c.x = nullptr; c.w = static_cast<const uint8_t*>(p3.w); c.bias = p3.bias; c.res = residual; c.y32 = out.y32;
     c.ysplit = static_cast<uint8_t*>(out.ysplit); c.post_scale = out.post_scale; c.post_shift = out.post_shift;

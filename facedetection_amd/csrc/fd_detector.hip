@@ -34,7 +34,7 @@ struct Tap {
 
 enum NetBuf {
     NB_STAGED = 0, NB_CONV0, NB_XA, NB_XB, NB_T1, NB_T2, NB_SC, NB_RPN_HID, NB_RPN_OUT, NB_ROIS, NB_ROI_SCORES,
-    NB_POOLED, NB_X4A, NB_X4B, NB_FLAT, NB_CLS, NB_BOX, NB_COUNTS, NB_ACT_A, NB_ACT_B, NB_COUNT
+    NB_POOLED, NB_X4A, NB_X4B, NB_FLAT, NB_CLS, NB_BOX, NB_COUNTS, NB_ACT_A, NB_ACT_B, NB_SPLITK, NB_COUNT
 };
 
 }  // namespace fd
@@ -273,6 +273,14 @@ struct Plan {
         }
         return static_cast<float*>(d->net[id].ptr);
     }
+    // output descriptor of a split-precision convolution, carrying the split-K workspace
+    static constexpr size_t SPLITK_FLOATS = size_t(32) << 20;   // 128 MB: the ROI head of 24 frames x 10 rois
+    SplitConvOut out() {
+        SplitConvOut o;
+        o.splitk_ws = buf(NB_SPLITK, SPLITK_FLOATS);
+        o.splitk_ws_floats = SPLITK_FLOATS;
+        return o;
+    }
     void tap(const char* name, const float* p, int64_t a, int64_t b, int64_t c, int64_t e) {
         if (dry) return;
         if (d->keep_taps) {
@@ -429,14 +437,14 @@ static int run_unit_split(Plan& pl, const Unit& u, const char* name, const void*
     if (u.has_sc) {
         float* s = pl.buf(NB_SC, (size_t)n * ho * wo * cout);
         if (!pl.dry) {
-            SplitConvOut o;
+            SplitConvOut o = pl.out();
             o.y32 = s;
             FD_TRY(split_conv_forward(u.s_sc, act, n, h, w, nullptr, o, pl.stream));
         }
         res = s;
     }
     if (!pl.dry) {
-        SplitConvOut o1, o2, o3;
+        SplitConvOut o1 = pl.out(), o2 = pl.out(), o3 = pl.out();
         o1.ysplit = t1;
         o2.ysplit = t2;
         o3.y32 = y32;
@@ -468,6 +476,7 @@ static int run_graph_split(Plan& pl, const uint8_t* frames, int B, int H, int W,
     const int R = d->prop.post_nms_top_n;
     const bool keep = d->keep_taps;
     float* staged = pl.buf(NB_STAGED, (size_t)B * H * W * 4);
+    (void)pl.out();                        // sizes the split-K workspace during the dry run
     if (!pl.dry) FD_TRY(stage_input_split(frames, B, H, W, d->norm, staged, pl.stream));
     const int h1 = d->s_conv0.s.out_h(H), w1 = d->s_conv0.s.out_w(W);
     // Stem and max-pool run as one kernel.  When intermediate tensors are kept for inspection the
@@ -475,7 +484,7 @@ static int run_graph_split(Plan& pl, const uint8_t* frames, int B, int H, int W,
     const bool fused_stem = !keep && (size_t)B * H * W * 16 < (1ull << 31);
     float* c0 = fused_stem ? nullptr : pl.buf(NB_CONV0, (size_t)B * h1 * w1 * FILTERS[0]);
     if (!pl.dry && !fused_stem) {
-        SplitConvOut o;
+        SplitConvOut o = pl.out();
         o.y32 = c0;
         FD_TRY(split_conv_forward(d->s_conv0, staged, B, H, W, nullptr, o, pl.stream));
     }
@@ -529,7 +538,7 @@ static int run_graph_split(Plan& pl, const uint8_t* frames, int B, int H, int W,
     float* hid = pl.buf(NB_RPN_HID, (size_t)B * fh * fw * 512);
     float* rout = pl.buf(NB_RPN_OUT, (size_t)B * fh * fw * 6 * A);
     if (!pl.dry) {
-        SplitConvOut o1, o2;
+        SplitConvOut o1 = pl.out(), o2 = pl.out();
         o1.ysplit = hid;
         o2.y32 = rout;
         FD_TRY(split_conv_forward(d->s_rpn_conv, feat_split, B, fh, fw, nullptr, o1, pl.stream));

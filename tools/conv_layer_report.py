@@ -3,9 +3,10 @@
 
     python tools/conv_layer_report.py <kernel_trace.csv> [micro_batch]
 
-Takes the conv_igemm launches of the last complete forward pass in the trace, pairs them with
-the layer list of faster_rcnn50 at 1080p (same order as the library issues them) and prints
-duration and achieved TFLOP/s per layer."""
+Takes the convolution launches of the last complete forward pass in the trace, pairs them with
+the layer list of faster_rcnn50 at 1080p (same order as the library issues them; the stem runs
+fused with the max-pool, conv2+conv3 of the 64-channel units as one kernel) and prints duration
+and achieved TFLOP/s per layer.  Use a single-stream trace (bench.py --streams 1)."""
 import csv
 import sys
 
@@ -38,6 +39,10 @@ def layer_list(B, H=1080, W=1920, R=10):
             conv(nm + "_c1", n, h, w, cin, mid, 1, 1, 0)
             h2, w2 = conv(nm + "_c2", n, h, w, mid, mid, 3, st, 1)
             conv(nm + "_c3", n, h2, w2, mid, cout, 1, 1, 0)
+            if mid == 64 and st == 1:
+                # conv2 and conv3 of the 64-channel bottlenecks run as one fused kernel
+                c3, c2 = layers.pop(), layers.pop()
+                layers.append((nm + "_c2c3", c2[1], c3[2], c2[3], c2[4] + c3[4]))
             h, w, cin = h2, w2, cout
     return layers
 
@@ -45,7 +50,8 @@ def layer_list(B, H=1080, W=1920, R=10):
 def main():
     path = sys.argv[1]
     B = int(sys.argv[2]) if len(sys.argv) > 2 else 8
-    rows = [r for r in csv.DictReader(open(path)) if "conv_igemm" in r["Kernel_Name"] or "conv_split_" in r["Kernel_Name"]]
+    rows = [r for r in csv.DictReader(open(path))
+            if any(t in r["Kernel_Name"] for t in ("conv_igemm", "conv_split_", "stem_pool", "conv_tail_fused"))]
     layers = layer_list(B)
     last = rows[-len(layers):]
     tot = totf = 0.0
