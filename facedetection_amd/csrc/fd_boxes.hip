@@ -130,10 +130,42 @@ __global__ __launch_bounds__(SORT_THREADS) void sort_scatter_kernel(const K* __r
     }
 }
 
+// Short segments (the detector tail sorts 10 rois per image): one workgroup per segment ranks
+// every element against all others in LDS -- rank = number of smaller keys + number of equal keys
+// at lower positions, i.e. the same stable order as the radix passes -- in a single launch
+// instead of eight.
+constexpr int SORT_SMALL_MAX = 2048;
+template <typename K>
+__global__ __launch_bounds__(256) void sort_small_kernel(K* __restrict__ keys, uint32_t* __restrict__ vals, int n) {
+    __shared__ K sk[SORT_SMALL_MAX];
+    __shared__ uint32_t sv[SORT_SMALL_MAX];
+    const int seg = blockIdx.x, tid = threadIdx.x;
+    K* k = keys + (size_t)seg * n;
+    uint32_t* v = vals + (size_t)seg * n;
+    for (int i = tid; i < n; i += 256) { sk[i] = k[i]; sv[i] = v[i]; }
+    __syncthreads();
+    for (int i = tid; i < n; i += 256) {
+        const K ki = sk[i];
+        int rank = 0;
+        for (int j = 0; j < n; ++j) {
+            const K kj = sk[j];
+            rank += (kj < ki || (kj == ki && j < i)) ? 1 : 0;
+        }
+        k[rank] = ki;
+        v[rank] = sv[i];
+    }
+}
+
 template <typename K>
 static int sort_pairs(fd_ctx* ctx, K* keys_a, uint32_t* vals_a, K* keys_b, uint32_t* vals_b, int n, int nseg,
                       hipStream_t stream) {
     if (n <= 0 || nseg <= 0) return FD_OK;
+    if (n <= SORT_SMALL_MAX) {
+        ProfScope scope(stream, "sort_small", 0.0, 2.0 * (sizeof(K) + 4.0) * n * nseg);
+        hipLaunchKernelGGL(sort_small_kernel<K>, dim3(nseg), dim3(256), 0, stream, keys_a, vals_a, n);
+        FD_LAUNCH_CHECK();
+        return FD_OK;
+    }
     const int nblk = ceil_div(n, SORT_TILE);
     uint32_t* hist = nullptr;
     FD_TRY(scratch_as(ctx, SLOT_SORT_HIST, (size_t)nseg * 256 * nblk, &hist));
