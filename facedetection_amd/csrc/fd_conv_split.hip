@@ -350,6 +350,7 @@ __device__ __forceinline__ void split_mma_step(const char* stage, const int (&a_
         bh[ni] = *reinterpret_cast<const f16x8*>(stage + b_off[0] + ni * 2048);
         bl[ni] = *reinterpret_cast<const f16x8*>(stage + b_off[1] + ni * 2048);
     }
+    __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int mi = 0; mi < AM; ++mi)
 #pragma unroll
@@ -358,6 +359,7 @@ __device__ __forceinline__ void split_mma_step(const char* stage, const int (&a_
             acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[mi], bl[ni], acc[mi][ni], 0, 0, 0);
             acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[mi], bh[ni], acc[mi][ni], 0, 0, 0);
         }
+    __builtin_amdgcn_s_setprio(0);
 }
 
 // Epilogue of a 16x16-block tile: transpose each wave's rows through its slice of LDS (32 rows
