@@ -8,7 +8,8 @@ import os
 import threading
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG, "libfacedet.so")
+# FD_LIBRARY selects another build of the library (A/B timing of kernel variants on one box)
+LIB_PATH = os.environ.get("FD_LIBRARY") or os.path.join(_PKG, "libfacedet.so")
 
 c_f32p = C.POINTER(C.c_float)
 c_f64p = C.POINTER(C.c_double)

@@ -796,10 +796,10 @@ __global__ __launch_bounds__(256, 2) void conv_split_reg_kernel(SplitKArgs a, un
             f16x4 h_, l_;                                                                         \
             if (MODE == REG_PRE) {                                                                \
                 _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                   \
-                    float t_ = fmaxf(ra[i][j] * psc[j] + psh[j], 0.f);                            \
+                    float t_ = ra[i][j] * psc[j] + psh[j];                                        \
                     if (!((lok >> i) & 1u)) t_ = 0.f;                                             \
                     _Float16 hh_, ll_;                                                            \
-                    split_f32(t_, hh_, ll_);                                                      \
+                    split_f32_relu(t_, hh_, ll_);                                                 \
                     h_[j] = hh_; l_[j] = ll_;                                                     \
                 }                                                                                 \
             } else {                                                                              \

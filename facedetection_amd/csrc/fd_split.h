@@ -35,6 +35,13 @@ __device__ __forceinline__ void split_f32(float v, _Float16& hi, _Float16& lo) {
     lo = (_Float16)(v - (float)hi);
 }
 
+// relu(v) split: the ReLU and the upper clamp are one median-of-three
+__device__ __forceinline__ void split_f32_relu(float v, _Float16& hi, _Float16& lo) {
+    v = __builtin_amdgcn_fmed3f(v, 0.0f, F16_MAX);
+    hi = (_Float16)v;
+    lo = (_Float16)(v - (float)hi);
+}
+
 // 8 consecutive channels -> 8 hi halves + 8 lo halves (16 bytes each)
 __device__ __forceinline__ void split8(const f32x4& a, const f32x4& b, f16x8& hi, f16x8& lo) {
 #pragma unroll
