@@ -362,8 +362,6 @@ __device__ __forceinline__ void split_mma_step(const char* stage, const int (&a_
     __builtin_amdgcn_s_setprio(0);
 }
 
-// Epilogue of a 16x16-block tile: transpose each wave's rows through its slice of LDS (32 rows
-// at a time); every lane then owns 8 consecutive channels of a row.
 // The residual values a lane adds in the epilogue, fetched ahead of time by kernels whose
 // per-workgroup chain of memory round trips would otherwise be exposed.
 template <int BM, int BN>
@@ -389,6 +387,8 @@ __device__ __forceinline__ void split_residual_prefetch(const SplitKArgs& a, int
         }
 }
 
+// Epilogue of a 16x16-block tile: transpose each wave's rows through its slice of LDS (32 rows
+// at a time); every lane then owns 8 consecutive channels of a row.
 template <int BM, int BN, bool PREFETCHED = false>
 __device__ __forceinline__ void split_epilogue16(const SplitKArgs& a, float* smem, int tile_m, int tile_n, int wave,
                                                  int lane, f32x4 (&acc)[BM / 32][BN / 32],
@@ -459,8 +459,10 @@ __device__ __forceinline__ void split_epilogue16(const SplitKArgs& a, float* sme
             if (row < a.M && col_ok) {
                 if (a.y32) {
                     float* yp = a.y32 + (size_t)row * a.Cout + gcol;
-                    *reinterpret_cast<f32x4*>(yp) = v0;
-                    *reinterpret_cast<f32x4*>(yp + 4) = v1;
+                    // streaming stores: the float32 tensor is far larger than the caches and is next
+                    // read several kernels later (+0.5 % frames/s against plain stores, same box)
+                    __builtin_nontemporal_store(v0, reinterpret_cast<f32x4*>(yp));
+                    __builtin_nontemporal_store(v1, reinterpret_cast<f32x4*>(yp + 4));
                 }
                 if (a.ysplit) {
                     if (post) {
