@@ -51,7 +51,11 @@ int stage_input_split(const uint8_t* frames, int batch, int h, int w, const Inpu
 // The 7x7/2 stem (bn0+ReLU folded) and the 3x3/2 max-pool in one kernel: staged split image ->
 // pooled split activations with relu(x * post_scale + post_shift) applied (and float32 pooled
 // values when y32 is given).
-int stem_pool_forward(const SplitConvParams& p, const void* staged_split, int batch, int h, int w,
+// (input: the planar staged image written by stage_input_planar)
+int staged_planar_width(int w);
+int stage_input_planar(const uint8_t* frames, int batch, int h, int w, const InputNorm& norm, void* y,
+                       hipStream_t stream);
+int stem_pool_forward(const SplitConvParams& p, const void* staged_planar, int batch, int h, int w,
                       const float* post_scale, const float* post_shift, float* y32, void* ysplit,
                       hipStream_t stream);
 

@@ -1421,6 +1421,48 @@ int stage_input_split(const uint8_t* frames, int batch, int h, int w, const Inpu
 }
 
 // ---------------------------------------------------------------------------------
+// uint8 frames -> planar staged image for the fused stem: a plane of hi halves and a plane of
+// lo halves, each [B][H][Wpad][4] fp16 with the pixel (y, x) in column x + 3 and zeros in the
+// other columns (the convolution's horizontal padding, stored), bn_data applied.
+int staged_planar_width(int w) { return (w + 8 + 1) & ~1; }
+
+__global__ __launch_bounds__(256) void stage_input_planar_kernel(const uint8_t* __restrict__ f, int W, int Wpad,
+                                                                long long slots, InputNorm n, f16x4* __restrict__ hi,
+                                                                f16x4* __restrict__ lo) {
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;      // one slot (row, column) of a plane
+    if (t >= slots) return;
+    const int col = (int)(t % Wpad);
+    const long long row = t / Wpad;                                      // image row over the whole batch
+    f16x4 h = {(_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f}, l = h;
+    const int x = col - 3;
+    if ((unsigned)x < (unsigned)W) {
+        const uint8_t* p = f + (row * W + x) * 3;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            _Float16 a, b;
+            split_f32((float)p[c] * n.scale[c] + n.shift[c], a, b);
+            h[c] = a;
+            l[c] = b;
+        }
+    }
+    hi[t] = h;
+    lo[t] = l;
+}
+
+int stage_input_planar(const uint8_t* frames, int batch, int h, int w, const InputNorm& norm, void* y,
+                       hipStream_t stream) {
+    FD_REQUIRE(frames && y, "stage_input_planar: NULL tensor");
+    const int wpad = staged_planar_width(w);
+    const long long slots = (long long)batch * h * wpad;
+    ProfScope scope(stream, "stage_input", 0.0, 3.0 * batch * h * (double)w + 16.0 * (double)slots);
+    f16x4* hi = static_cast<f16x4*>(y);
+    hipLaunchKernelGGL(stage_input_planar_kernel, dim3((unsigned)ceil_div(slots, 256)), dim3(256), 0, stream, frames, w,
+                       wpad, slots, norm, hi, hi + slots);
+    FD_LAUNCH_CHECK();
+    return FD_OK;
+}
+
+// ---------------------------------------------------------------------------------
 // 3x3/2 max pooling of a float32 map, written as float32 (optional) and as the split of
 // relu(max * scale[c] + shift[c]) for the first residual unit.
 __global__ __launch_bounds__(256) void maxpool_split_kernel(const float* __restrict__ x, int B, int H, int W, int C, int Ho,
@@ -1483,7 +1525,7 @@ __global__ __launch_bounds__(256) void maxpool_split_kernel(const float* __restr
 // of post-ReLU values.  This removes the write and the re-read of the 64-channel full-resolution
 // tensor (2.1 GB per 8 frames at 1080p).
 struct StemPoolArgs {
-    const uint8_t* x;        // split staged image [B][H][W][4 hi | 4 lo]
+    const uint8_t* x;        // planar staged image: hi plane [B][H][Wpad][4 halves], then the lo plane
     const uint8_t* w;        // split packed stem weights [64][7][8][4]
     const float* bias;       // bn0 shift
     const float* post_scale; // bn1 of the first unit, applied to the split output
@@ -1492,6 +1534,8 @@ struct StemPoolArgs {
     uint8_t* ysplit;         // pooled split output
     float w_inv_scale;
     int H, W, Ho, Wo, Hp, Wp, tiles_y, tiles_x;
+    int Wpad;                // columns per staged row: 3 zero columns, W pixels, zero columns up to Wpad
+    unsigned plane_bytes;    // size of one plane
 };
 
 template <int PH, int PW>
@@ -1517,23 +1561,26 @@ __global__ __launch_bounds__(256, 2) void stem_pool_kernel(StemPoolArgs a, unsig
     const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, w_bytes, 0x00020000);
     constexpr unsigned OOB = 0x80000000u;
 
-    // activations: thread -> patch rows r0 + 32 i, kernel column c4 (k = 4 c4 + c inside a kernel row)
-    const int c4 = tid & 7, r0 = tid >> 3;
-    int hi0[RA], wi0[RA];
-    unsigned abase[RA], a_lds[RA];
+    // activations by LDS-DMA.  In the planar image the 8 pixels of a kernel row are 64 contiguous
+    // bytes in the hi plane and 64 in the lo plane, which is exactly a staged row [32 hi | 32 lo]:
+    // the lane at chunk position p of row r fetches chunk c = p ^ ((r >> 1) & 7), i.e. pixels
+    // 2 (c & 3), 2 (c & 3) + 1 of plane c >> 2.  The zero columns of the image stand in for the
+    // horizontal padding; rows above / below the image go out of range and read zeros.
+    const int lrow = lane >> 3, lpos = lane & 7;
+    int hi0[RA];
+    int abase[RA];
     bool mval[RA];
 #pragma unroll
     for (int i = 0; i < RA; ++i) {
-        const int row = r0 + 32 * i;
+        const int row = (wave + 4 * i) * 8 + lrow;
+        const int c = lpos ^ ((row >> 1) & 7);
         const int pr = row / CW, pc = row - pr * CW;
         const int oy = oy0 + pr, ox = ox0 + pc;
         mval[i] = row < CH * CW && (unsigned)oy < (unsigned)a.Ho && (unsigned)ox < (unsigned)a.Wo;
         hi0[i] = oy * 2 - 3;
-        wi0[i] = ox * 2 - 3;
-        abase[i] = (unsigned)(((img * a.H + hi0[i]) * a.W + wi0[i]) * 16 + c4 * 16);
-        a_lds[i] = (unsigned)(row * 128 + (((c4 >> 1) ^ ((row >> 1) & 7)) * 16) + (c4 & 1) * 8);
+        // pixel x lives in column x + 3, so the window's first column is 2 ox: 16-byte aligned
+        abase[i] = (int)((c >> 2) * a.plane_bytes) + ((img * a.H + hi0[i]) * a.Wpad + ox * 2 + 2 * (c & 3)) * 8;
     }
-    const int lrow = lane >> 3, lpos = lane & 7;
     unsigned bvo[GB];
 #pragma unroll
     for (int i = 0; i < GB; ++i) {
@@ -1541,31 +1588,20 @@ __global__ __launch_bounds__(256, 2) void stem_pool_kernel(StemPoolArgs a, unsig
         bvo[i] = (unsigned)(row * 224 * 4 + (lpos ^ ((row >> 1) & 7)) * 16);
     }
     constexpr int NK = 7;                             // one K-step per kernel row
-    f32x4 ra[RA];
 
-#define FD_GLOAD(KT, STG)                                                                         \
+#define FD_ISSUE(KT, STG)                                                                         \
     do {                                                                                          \
-        _Pragma("unroll") for (int i = 0; i < RA; ++i) {                                          \
-            const int hi_ = hi0[i] + (KT), wi_ = wi0[i] + c4;                                     \
-            const bool ok_ = mval[i] && (unsigned)hi_ < (unsigned)a.H && (unsigned)wi_ < (unsigned)a.W; \
-            const unsigned vo_ = ok_ ? abase[i] + (unsigned)((KT) * a.W * 16) : OOB;              \
-            ra[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xr, vo_, 0, 0)); \
-        }                                                                                         \
         float* sa_ = smem + (STG) * STAGE;                                                        \
+        _Pragma("unroll") for (int i = 0; i < RA; ++i) {                                          \
+            const bool ok_ = mval[i] && (unsigned)(hi0[i] + (KT)) < (unsigned)a.H;                \
+            const unsigned vo_ = ok_ ? (unsigned)(abase[i] + (KT) * a.Wpad * 8) : OOB;            \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(                                             \
+                xr, (__attribute__((address_space(3))) void*)(sa_ + (wave + 4 * i) * 256), 16, vo_, 0, 0, 0); \
+        }                                                                                         \
         _Pragma("unroll") for (int i = 0; i < GB; ++i)                                            \
             __builtin_amdgcn_raw_ptr_buffer_load_lds(                                             \
                 wr, (__attribute__((address_space(3))) void*)(sa_ + BM * 32 + (wave + 4 * i) * 256), 16, \
                 bvo[i], (KT) * 128, 0, 0);                                                        \
-    } while (0)
-
-#define FD_LSTORE(STG)                                                                            \
-    do {                                                                                          \
-        char* sb_ = reinterpret_cast<char*>(smem) + (STG) * STAGE * 4;                            \
-        _Pragma("unroll") for (int i = 0; i < RA; ++i) {                                          \
-            const float2 p0_ = make_float2(ra[i][0], ra[i][1]), p1_ = make_float2(ra[i][2], ra[i][3]); \
-            *reinterpret_cast<float2*>(sb_ + a_lds[i]) = p0_;                                     \
-            *reinterpret_cast<float2*>(sb_ + (a_lds[i] ^ 64u)) = p1_;                             \
-        }                                                                                         \
     } while (0)
 
     f32x4 acc[T::AM][T::AN];
@@ -1584,21 +1620,18 @@ __global__ __launch_bounds__(256, 2) void stem_pool_kernel(StemPoolArgs a, unsig
         b_off[part] = (BM + wn * (BN / 2) + frow) * 128 + pos;
     }
 
-    FD_GLOAD(0, 0);
-    FD_LSTORE(0);
+    FD_ISSUE(0, 0);
     wait_vmcnt<0>();
     __syncthreads();
 #pragma unroll
     for (int kt = 0; kt < NK; ++kt) {
         const int cur = kt & 1;
-        if (kt + 1 < NK) FD_GLOAD(kt + 1, cur ^ 1);
+        if (kt + 1 < NK) FD_ISSUE(kt + 1, cur ^ 1);
         split_mma_step<BM, BN>(sbase + cur * STAGE * 4, a_off, b_off, acc);
-        if (kt + 1 < NK) FD_LSTORE(cur ^ 1);
         wait_vmcnt<0>();
         __syncthreads();
     }
-#undef FD_GLOAD
-#undef FD_LSTORE
+#undef FD_ISSUE
 
     // the convolution patch, bias + ReLU applied, as float32 rows of LDP floats
     float* patch = smem;
@@ -1667,25 +1700,27 @@ __global__ __launch_bounds__(256, 2) void stem_pool_kernel(StemPoolArgs a, unsig
 #endif
 }
 
-int stem_pool_forward(const SplitConvParams& p, const void* staged_split, int batch, int h, int w,
+int stem_pool_forward(const SplitConvParams& p, const void* staged_planar, int batch, int h, int w,
                       const float* post_scale, const float* post_shift, float* y32, void* ysplit,
                       hipStream_t stream) {
     const ConvShape& s = p.s;
-    FD_REQUIRE(staged_split && p.w && ysplit, "stem+pool: NULL tensor");
+    FD_REQUIRE(staged_planar && p.w && ysplit, "stem+pool: NULL tensor");
     FD_REQUIRE(s.cin == 4 && s.kwp == 8 && s.kh == 7 && s.kw == 7 && s.stride == 2 && s.pad == 3 && s.cout == 64 &&
                    p.relu,
                "stem+pool: this kernel is the 7x7/2 stem with 64 output channels and ReLU");
     constexpr int PH = 5, PW = 11;
     StemPoolArgs a;
-    a.x = static_cast<const uint8_t*>(staged_split);
+    a.x = static_cast<const uint8_t*>(staged_planar);
     a.w = static_cast<const uint8_t*>(p.w);
     a.bias = p.bias; a.post_scale = post_scale; a.post_shift = post_shift;
+    a.Wpad = staged_planar_width(w);
     a.y32 = y32; a.ysplit = static_cast<uint8_t*>(ysplit); a.w_inv_scale = p.w_inv_scale;
     a.H = h; a.W = w; a.Ho = s.out_h(h); a.Wo = s.out_w(w);
     a.Hp = (a.Ho + 2 - 3) / 2 + 1; a.Wp = (a.Wo + 2 - 3) / 2 + 1;
     a.tiles_y = ceil_div(a.Hp, PH); a.tiles_x = ceil_div(a.Wp, PW);
-    const size_t x_bytes = (size_t)batch * h * w * 16, w_bytes = s.packed_floats() * 4;
+    const size_t x_bytes = (size_t)batch * h * a.Wpad * 16, w_bytes = s.packed_floats() * 4;
     FD_REQUIRE(x_bytes < (1ull << 31), "stem+pool: staged batch too large for 32-bit offsets");
+    a.plane_bytes = (unsigned)(x_bytes / 2);
     const long long grid = (long long)batch * a.tiles_y * a.tiles_x;
     FD_REQUIRE(grid < (1ll << 31), "stem+pool: too many tiles");
     ProfScope scope(stream, "stem_pool", 2.0 * batch * a.Ho * a.Wo * 64.0 * 147.0,

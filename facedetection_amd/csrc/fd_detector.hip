@@ -475,13 +475,18 @@ static int run_graph_split(Plan& pl, const uint8_t* frames, int B, int H, int W,
     fd_detector* d = pl.d;
     const int R = d->prop.post_nms_top_n;
     const bool keep = d->keep_taps;
-    float* staged = pl.buf(NB_STAGED, (size_t)B * H * W * 4);
     (void)pl.out();                        // sizes the split-K workspace during the dry run
-    if (!pl.dry) FD_TRY(stage_input_split(frames, B, H, W, d->norm, staged, pl.stream));
     const int h1 = d->s_conv0.s.out_h(H), w1 = d->s_conv0.s.out_w(W);
-    // Stem and max-pool run as one kernel.  When intermediate tensors are kept for inspection the
-    // two-kernel form is used instead, because only it materialises the convolution output.
-    const bool fused_stem = !keep && (size_t)B * H * W * 16 < (1ull << 31);
+    // Stem and max-pool run as one kernel on a planar staged image.  When intermediate tensors are
+    // kept for inspection the two-kernel form is used instead, because only it materialises the
+    // convolution output.
+    const size_t planar_floats = (size_t)B * H * staged_planar_width(W) * 4;
+    const bool fused_stem = !keep && planar_floats * 4 < (1ull << 31);
+    float* staged = pl.buf(NB_STAGED, fused_stem ? planar_floats : (size_t)B * H * W * 4);
+    if (!pl.dry) {
+        if (fused_stem) FD_TRY(stage_input_planar(frames, B, H, W, d->norm, staged, pl.stream));
+        else FD_TRY(stage_input_split(frames, B, H, W, d->norm, staged, pl.stream));
+    }
     float* c0 = fused_stem ? nullptr : pl.buf(NB_CONV0, (size_t)B * h1 * w1 * FILTERS[0]);
     if (!pl.dry && !fused_stem) {
         SplitConvOut o = pl.out();
