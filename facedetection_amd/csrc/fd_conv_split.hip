@@ -372,18 +372,20 @@ __device__ __forceinline__ void split_residual_prefetch(const SplitKArgs& a, int
     const int erow = lane / E::L8, ecol = (lane % E::L8) * 8;
     const int gcol = tile_n * BN + wn * E::WN + ecol;
     const bool col_ok = gcol < a.Cout;
+    // Every lane issues every load (rows beyond M and columns beyond Cout read a clamped address
+    // and are zeroed afterwards): callers count these loads in their s_waitcnt vmcnt values, so
+    // their number must not depend on the tile.
+    const int safe_col = col_ok ? gcol : 0;
 #pragma unroll
     for (int mi = 0; mi < E::GROUPS; ++mi)
 #pragma unroll
         for (int ps = 0; ps < E::PASSES; ++ps) {
             const int row = tile_m * BM + wm * (BM / 2) + mi * 32 + ps * E::RPP + erow;
-            res[mi][ps][0] = f32x4{0.f, 0.f, 0.f, 0.f};
-            res[mi][ps][1] = res[mi][ps][0];
-            if (a.res && row < a.M && col_ok) {
-                const float* rp = a.res + (size_t)row * a.Cout + gcol;
-                res[mi][ps][0] = *reinterpret_cast<const f32x4*>(rp);
-                res[mi][ps][1] = *reinterpret_cast<const f32x4*>(rp + 4);
-            }
+            const bool ok = row < a.M && col_ok;
+            const float* rp = a.res + (size_t)(row < a.M ? row : a.M - 1) * a.Cout + safe_col;
+            const f32x4 r0 = *reinterpret_cast<const f32x4*>(rp), r1 = *reinterpret_cast<const f32x4*>(rp + 4);
+            res[mi][ps][0] = ok ? r0 : f32x4{0.f, 0.f, 0.f, 0.f};
+            res[mi][ps][1] = ok ? r1 : f32x4{0.f, 0.f, 0.f, 0.f};
         }
 }
 
@@ -1278,6 +1280,7 @@ int conv_tail_fused_forward(const SplitConvParams& p2, const SplitConvParams& p3
     const size_t x_bytes = (size_t)m_ll * 64 * 4, w_bytes = s2.packed_floats() * 4, w3_bytes = s3.packed_floats() * 4;
     if (x_bytes >= (1ull << 31) || (size_t)m_ll * s3.cout * 4 >= (1ull << 33) || m_ll >= (1ll << 29)) return FD_OK;
     FD_REQUIRE(x_split && p2.w && p3.w && (out.y32 || out.ysplit), "fused tail: NULL tensor");
+    if (!residual) return FD_OK;       // the kernel's load counting assumes a residual tensor
     SplitKArgs a, c;
     a.x = static_cast<const uint8_t*>(x_split); a.w = static_cast<const uint8_t*>(p2.w);
     a.bias = p2.bias; a.res = nullptr; a.y32 = nullptr; a.ysplit = nullptr; a.post_scale = a.post_shift = nullptr;
