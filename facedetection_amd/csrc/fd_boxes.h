@@ -50,5 +50,9 @@ int postprocess_run(fd_ctx* ctx, const float* rois, int roi_stride, const float*
 // ROI max pooling, channels-last: data [batch][H][W][C] -> out [num_rois][ph][pw][C].
 int roipool_nhwc(const float* data, int batch, int channels, int height, int width, const float* rois, int num_rois,
                  int pooled_h, int pooled_w, float spatial_scale, float* out, hipStream_t stream);
+// Pooling written directly as split(relu(max * bn_scale[c] + bn_shift[c])) (channels % 32 == 0).
+int roipool_nhwc_split(const float* data, int batch, int channels, int height, int width, const float* rois,
+                       int num_rois, int pooled_h, int pooled_w, float spatial_scale, const float* bn_scale,
+                       const float* bn_shift, void* out_split, hipStream_t stream);
 
 }  // namespace fd

@@ -8,6 +8,7 @@
 // has to round exactly where NumPy rounds (one rounding per +, -, *, /), so no a*b+c may
 // be fused.  (The build also passes -ffp-contract=off.)
 #include "fd_boxes.h"
+#include "fd_split.h"
 
 #include <cfloat>
 #include <cmath>
@@ -970,6 +971,64 @@ __global__ __launch_bounds__(256) void roipool_nhwc_kernel(const float* __restri
         }
         o[c4] = m;
     }
+}
+
+// The same pooling written as split(relu(max * bn_scale[c] + bn_shift[c])): the form the ROI head's
+// first convolutions read.  One workgroup per (roi, bin) as above (one workgroup per roi sweeping
+// its bins measured 1.7x slower: too few loads in flight); threads sweep the channels 8 at a time,
+// each writing one 16-byte hi and one 16-byte lo chunk.
+__global__ __launch_bounds__(128) void roipool_nhwc_split_kernel(const float* __restrict__ data, int batch, int C, int H,
+                                                                int W, const float* __restrict__ rois, int PH, int PW,
+                                                                float scale, const float* __restrict__ bn_scale,
+                                                                const float* __restrict__ bn_shift,
+                                                                uint8_t* __restrict__ out) {
+    const int bin = blockIdx.x, n = blockIdx.y;
+    const RoiBin r = roi_bin(rois + (size_t)n * 5, scale, bin / PW, bin % PW, PH, PW, H, W, batch);
+    uint8_t* o = out + ((size_t)n * PH * PW + bin) * C * 4;
+    for (int c8 = threadIdx.x; c8 < C / 8; c8 += 128) {
+        f32x4 m0 = {0.f, 0.f, 0.f, 0.f}, m1 = m0;
+        if (!r.empty) {
+            m0 = f32x4{-FLT_MAX, -FLT_MAX, -FLT_MAX, -FLT_MAX};
+            m1 = m0;
+            for (int h = r.hstart; h < r.hend; ++h) {
+                const f32x4* row = reinterpret_cast<const f32x4*>(data + ((size_t)r.b * H + h) * W * C) + c8 * 2;
+                for (int w = r.wstart; w < r.wend; ++w) {
+                    const f32x4* px = row + (size_t)w * (C / 4);
+                    const f32x4 v0 = px[0], v1 = px[1];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { m0[j] = fmaxf(m0[j], v0[j]); m1[j] = fmaxf(m1[j], v1[j]); }
+                }
+            }
+        }
+        const f32x4* sc = reinterpret_cast<const f32x4*>(bn_scale) + c8 * 2;
+        const f32x4* sh = reinterpret_cast<const f32x4*>(bn_shift) + c8 * 2;
+        const f32x4 s0 = sc[0], s1 = sc[1], t0 = sh[0], t1 = sh[1];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            // fused multiply-add, as the standalone float32 -> split conversion rounds
+            m0[j] = fmaxf(__builtin_fmaf(m0[j], s0[j], t0[j]), 0.f);
+            m1[j] = fmaxf(__builtin_fmaf(m1[j], s1[j], t1[j]), 0.f);
+        }
+        f16x8 hi, lo;
+        split8(m0, m1, hi, lo);
+        uint8_t* sp = o + split_offset(c8 * 8);
+        *reinterpret_cast<f16x8*>(sp) = hi;
+        *reinterpret_cast<f16x8*>(sp + 64) = lo;
+    }
+}
+
+int roipool_nhwc_split(const float* data, int batch, int C, int H, int W, const float* rois, int num_rois, int PH,
+                       int PW, float scale, const float* bn_scale, const float* bn_shift, void* out,
+                       hipStream_t stream) {
+    FD_REQUIRE(data && rois && out && bn_scale && bn_shift, "roipool: NULL argument");
+    FD_REQUIRE(C % 32 == 0 && C > 0, "roipool (split output): channel count %d must be a multiple of 32", C);
+    FD_REQUIRE(PH > 0 && PW > 0, "roipool (split output): bad bin grid");
+    if (num_rois <= 0) return FD_OK;
+    ProfScope scope(stream, "roipool", 0.0, 2.0 * 4.0 * (double)num_rois * PH * PW * C);
+    hipLaunchKernelGGL(roipool_nhwc_split_kernel, dim3(PH * PW, num_rois), dim3(128), 0, stream, data, batch, C, H, W,
+                       rois, PH, PW, scale, bn_scale, bn_shift, static_cast<uint8_t*>(out));
+    FD_LAUNCH_CHECK();
+    return FD_OK;
 }
 
 int roipool_nhwc(const float* data, int batch, int C, int H, int W, const float* rois, int num_rois, int PH, int PW,

@@ -490,6 +490,17 @@ __device__ __forceinline__ void wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
+// Workgroup barrier for the multi-stage LDS-DMA loops.  __syncthreads() carries fences that make
+// the compiler drain every vector-memory operation (s_waitcnt vmcnt(0)) while LDS-DMA is in
+// flight, which turns a three- or four-stage pipeline into a two-stage one; here only this wave's
+// LDS operations are drained, and LDS-DMA completion is the caller's business (wait_vmcnt before
+// the barrier).
+__device__ __forceinline__ void pipeline_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
 // ---------------------------------------------------------------------------------
 // Direct-to-LDS kernel (every layer whose input is already split).  Both operand tiles are
 // fetched with `buffer_load_dwordx4 ... lds`: no staging registers, no ds_write, and padding
@@ -634,7 +645,7 @@ __global__ __launch_bounds__(256, 2) void conv_split_glds_kernel(SplitKArgs a, u
         if ((KT) + NS - 1 < nk) FD_ISSUE((KT) + NS - 1, ((CUR) + NS - 1) % NS);                   \
         split_mma_step<BM, BN>(sbase + (CUR) * STAGE * 4, a_off, b_off, acc);                     \
         FD_WAIT(min(NS - 2, nk - 2 - (KT)));                                                      \
-        __syncthreads();                                                                          \
+        pipeline_barrier();                                                                       \
     } while (0)
 
     FD_TAP();
@@ -642,7 +653,7 @@ __global__ __launch_bounds__(256, 2) void conv_split_glds_kernel(SplitKArgs a, u
     for (int st = 0; st < NS - 1; ++st)
         if (st < nk) FD_ISSUE(st, st);
     FD_WAIT(min(NS - 2, nk - 1));
-    __syncthreads();
+    pipeline_barrier();
     for (int kt = 0; kt < nk; kt += NS) {
         FD_STEP(0, kt);
         if (kt + 1 < nk) FD_STEP(1, kt + 1);

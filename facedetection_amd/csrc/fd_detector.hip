@@ -567,17 +567,23 @@ static int run_graph_split(Plan& pl, const uint8_t* frames, int B, int H, int W,
     pl.tap("rois", rois, B, R, 5, 1);
     pl.tap("roi_scores", roi_scores, B, R, 1, 1);
     const int N = B * R;
-    float* pooled = pl.buf(NB_POOLED, (size_t)N * POOLED * POOLED * FILTERS[3]);
+    float* pooled = keep ? pl.buf(NB_POOLED, (size_t)N * POOLED * POOLED * FILTERS[3]) : nullptr;
     const size_t x4 = (size_t)N * POOLED * POOLED * FILTERS[4];
     float* x4buf[2] = {pl.buf(NB_X4A, x4), pl.buf(NB_X4B, x4)};
     float* a4buf[2] = {pl.buf(NB_ACT_A, x4), pl.buf(NB_ACT_B, x4)};
     if (!pl.dry) {
-        FD_TRY(roipool_nhwc(feat, B, FILTERS[3], fh, fw, rois, N, POOLED, POOLED, 1.0f / 16.0f, pooled, pl.stream));
-        // feat_split lives in one of the act buffers and is no longer needed: reuse them for stage 4
-        FD_TRY(to_split(pooled, (long long)N * POOLED * POOLED, FILTERS[3], d->stage[3][0].bn1_scale,
-                        d->stage[3][0].bn1_shift, a4buf[0], pl.stream));
+        // feat_split lives in one of the act buffers and is no longer needed: reuse them for stage 4.
+        // The float32 pooled tensor is only materialised for inspection.
+        if (keep) {
+            FD_TRY(roipool_nhwc(feat, B, FILTERS[3], fh, fw, rois, N, POOLED, POOLED, 1.0f / 16.0f, pooled, pl.stream));
+            FD_TRY(to_split(pooled, (long long)N * POOLED * POOLED, FILTERS[3], d->stage[3][0].bn1_scale,
+                            d->stage[3][0].bn1_shift, a4buf[0], pl.stream));
+        } else {
+            FD_TRY(roipool_nhwc_split(feat, B, FILTERS[3], fh, fw, rois, N, POOLED, POOLED, 1.0f / 16.0f,
+                                      d->stage[3][0].bn1_scale, d->stage[3][0].bn1_shift, a4buf[0], pl.stream));
+        }
     }
-    pl.tap("pooled", pooled, N, POOLED, POOLED, FILTERS[3]);
+    if (keep) pl.tap("pooled", pooled, N, POOLED, POOLED, FILTERS[3]);
     h = POOLED; w = POOLED;
     cur = 0;
     xraw = nullptr;
