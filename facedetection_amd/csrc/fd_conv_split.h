@@ -41,6 +41,12 @@ int conv_tail_fused_forward(const SplitConvParams& conv2, const SplitConvParams&
                             int h, int w, const float* residual, const SplitConvOut& out, hipStream_t stream,
                             bool* taken);
 
+// A whole identity-shortcut unit of the 64-channel stage (conv1 on the float32 input through
+// BatchNorm+ReLU, conv2, conv3 + the input as residual) in one kernel; *taken as above.
+int unit_fused_forward(const SplitConvParams& conv1, const SplitConvParams& conv2, const SplitConvParams& conv3,
+                       const float* x32, const float* pre_scale, const float* pre_shift, int batch, int h, int w,
+                       const SplitConvOut& out, hipStream_t stream, bool* taken);
+
 // float32 [rows][channels] -> split, optionally through relu(x * scale[c] + shift[c]).
 int to_split(const float* x, long long rows, int channels, const float* scale, const float* shift, void* y,
              hipStream_t stream);

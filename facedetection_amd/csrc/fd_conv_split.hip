@@ -362,27 +362,46 @@ __device__ __forceinline__ void split_mma_step(const char* stage, const int (&a_
     __builtin_amdgcn_s_setprio(0);
 }
 
+// Which row of the [M][Cout] output a tile-local row is (-1: none).  Linear tiles are BM
+// consecutive rows; pixel tiles are 8 x 16 patches of one image.
+struct LinearRows {
+    int base, M;
+    __device__ __forceinline__ int operator()(int local) const {
+        const int r = base + local;
+        return r < M ? r : -1;
+    }
+};
+struct PatchRows {
+    int pix0;          // output row of the tile's top-left pixel
+    int W;             // image width in pixels
+    int ymax, xmax;    // valid tile rows / columns (image edge)
+    __device__ __forceinline__ int operator()(int local) const {
+        const int ty = local >> 4, tx = local & 15;
+        return (ty < ymax && tx < xmax) ? pix0 + ty * W + tx : -1;
+    }
+};
+
 // The residual values a lane adds in the epilogue, fetched ahead of time by kernels whose
 // per-workgroup chain of memory round trips would otherwise be exposed.
-template <int BM, int BN>
-__device__ __forceinline__ void split_residual_prefetch(const SplitKArgs& a, int tile_m, int tile_n, int wave, int lane,
+template <int BM, int BN, class RM>
+__device__ __forceinline__ void split_residual_prefetch(const SplitKArgs& a, const RM& rm, int tile_n, int wave, int lane,
                                                         f32x4 (&res)[SplitEpi<BM, BN>::GROUPS][SplitEpi<BM, BN>::PASSES][2]) {
     using E = SplitEpi<BM, BN>;
     const int wm = wave >> 1, wn = wave & 1;
     const int erow = lane / E::L8, ecol = (lane % E::L8) * 8;
     const int gcol = tile_n * BN + wn * E::WN + ecol;
     const bool col_ok = gcol < a.Cout;
-    // Every lane issues every load (rows beyond M and columns beyond Cout read a clamped address
-    // and are zeroed afterwards): callers count these loads in their s_waitcnt vmcnt values, so
-    // their number must not depend on the tile.
+    // Every lane issues every load (rows outside the output and columns beyond Cout read a clamped
+    // address and are zeroed afterwards): callers count these loads in their s_waitcnt vmcnt
+    // values, so their number must not depend on the tile.
     const int safe_col = col_ok ? gcol : 0;
 #pragma unroll
     for (int mi = 0; mi < E::GROUPS; ++mi)
 #pragma unroll
         for (int ps = 0; ps < E::PASSES; ++ps) {
-            const int row = tile_m * BM + wm * (BM / 2) + mi * 32 + ps * E::RPP + erow;
-            const bool ok = row < a.M && col_ok;
-            const float* rp = a.res + (size_t)(row < a.M ? row : a.M - 1) * a.Cout + safe_col;
+            const int row = rm(wm * (BM / 2) + mi * 32 + ps * E::RPP + erow);
+            const bool ok = row >= 0 && col_ok;
+            const float* rp = a.res + (size_t)(row >= 0 ? row : 0) * a.Cout + safe_col;
             const f32x4 r0 = *reinterpret_cast<const f32x4*>(rp), r1 = *reinterpret_cast<const f32x4*>(rp + 4);
             res[mi][ps][0] = ok ? r0 : f32x4{0.f, 0.f, 0.f, 0.f};
             res[mi][ps][1] = ok ? r1 : f32x4{0.f, 0.f, 0.f, 0.f};
@@ -391,10 +410,10 @@ __device__ __forceinline__ void split_residual_prefetch(const SplitKArgs& a, int
 
 // Epilogue of a 16x16-block tile: transpose each wave's rows through its slice of LDS (32 rows
 // at a time); every lane then owns 8 consecutive channels of a row.
-template <int BM, int BN, bool PREFETCHED = false>
-__device__ __forceinline__ void split_epilogue16(const SplitKArgs& a, float* smem, int tile_m, int tile_n, int wave,
-                                                 int lane, f32x4 (&acc)[BM / 32][BN / 32],
-                                                 f32x4 (*pres)[SplitEpi<BM, BN>::PASSES][2] = nullptr) {
+template <int BM, int BN, bool PREFETCHED, class RM>
+__device__ __forceinline__ void split_epilogue16_rows(const SplitKArgs& a, float* smem, const RM& rm, int tile_n, int wave,
+                                                      int lane, f32x4 (&acc)[BM / 32][BN / 32],
+                                                      f32x4 (*pres)[SplitEpi<BM, BN>::PASSES][2] = nullptr) {
     using T = SplitTile<BM, BN>;
     constexpr int WN = T::WN, LDC = T::LDC, AN = T::AN;
     constexpr int L8 = WN / 8;
@@ -421,7 +440,7 @@ __device__ __forceinline__ void split_epilogue16(const SplitKArgs& a, float* sme
     }
 #pragma unroll
     for (int mi = 0; mi < BM / 64; ++mi) {
-        const int grow0 = tile_m * BM + wm * (BM / 2) + mi * 32;
+        const int lrow0 = wm * (BM / 2) + mi * 32;
         f32x4 res0[PASSES], res1[PASSES];
         if (PREFETCHED) {
 #pragma unroll
@@ -429,10 +448,10 @@ __device__ __forceinline__ void split_epilogue16(const SplitKArgs& a, float* sme
         } else if (a.res) {
 #pragma unroll
             for (int ps = 0; ps < PASSES; ++ps) {
-                const int row = grow0 + ps * RPP + erow;
+                const int row = rm(lrow0 + ps * RPP + erow);
                 res0[ps] = f32x4{0.f, 0.f, 0.f, 0.f};
                 res1[ps] = res0[ps];
-                if (row < a.M && col_ok) {
+                if (row >= 0 && col_ok) {
                     const float* rp = a.res + (size_t)row * a.Cout + gcol;
                     res0[ps] = *reinterpret_cast<const f32x4*>(rp);
                     res1[ps] = *reinterpret_cast<const f32x4*>(rp + 4);
@@ -454,11 +473,11 @@ __device__ __forceinline__ void split_epilogue16(const SplitKArgs& a, float* sme
 #pragma unroll
         for (int ps = 0; ps < PASSES; ++ps) {
             const int lrow2 = ps * RPP + erow;
-            const int row = grow0 + lrow2;
+            const int row = rm(lrow0 + lrow2);
             f32x4 v0 = *reinterpret_cast<const f32x4*>(&Cs[lrow2 * LDC + ecol]);
             f32x4 v1 = *reinterpret_cast<const f32x4*>(&Cs[lrow2 * LDC + ecol + 4]);
             if (a.res) { v0 += res0[ps]; v1 += res1[ps]; }
-            if (row < a.M && col_ok) {
+            if (row >= 0 && col_ok) {
                 if (a.y32) {
                     float* yp = a.y32 + (size_t)row * a.Cout + gcol;
                     // streaming stores: the float32 tensor is far larger than the caches and is next
@@ -483,6 +502,15 @@ __device__ __forceinline__ void split_epilogue16(const SplitKArgs& a, float* sme
             }
         }
     }
+}
+
+// the same for a tile of BM consecutive output rows
+template <int BM, int BN, bool PREFETCHED = false>
+__device__ __forceinline__ void split_epilogue16(const SplitKArgs& a, float* smem, int tile_m, int tile_n, int wave,
+                                                 int lane, f32x4 (&acc)[BM / 32][BN / 32],
+                                                 f32x4 (*pres)[SplitEpi<BM, BN>::PASSES][2] = nullptr) {
+    const LinearRows rm{tile_m * BM, a.M};
+    split_epilogue16_rows<BM, BN, PREFETCHED>(a, smem, rm, tile_n, wave, lane, acc, pres);
 }
 
 template <int N>
@@ -1260,7 +1288,7 @@ __global__ __launch_bounds__(256, 2) void conv_tail_fused_kernel(SplitKArgs a, S
         __syncthreads();               /* every wave is done reading the weight chunk */          \
         if ((CH) + 1 < nch) {                                                                     \
             FD_WEIGHTS((CH) + 1);                                                                 \
-            split_residual_prefetch<BM, BN>(c, tile_m, (CH) + 1, wave, lane, RNEXT);              \
+            split_residual_prefetch<BM, BN>(c, rows, (CH) + 1, wave, lane, RNEXT);              \
             __builtin_amdgcn_sched_barrier(0);                                                    \
         }                                                                                         \
         split_epilogue16<BM, BN, true>(c, smem, tile_m, (CH), wave, lane, acc3, RCUR);            \
@@ -1268,8 +1296,9 @@ __global__ __launch_bounds__(256, 2) void conv_tail_fused_kernel(SplitKArgs a, S
 
     const int nch = c.Cout / 64;
     f32x4 resA[E::GROUPS][E::PASSES][2], resB[E::GROUPS][E::PASSES][2];
+    const LinearRows rows{tile_m * BM, c.M};
     FD_WEIGHTS(0);
-    split_residual_prefetch<BM, BN>(c, tile_m, 0, wave, lane, resA);
+    split_residual_prefetch<BM, BN>(c, rows, 0, wave, lane, resA);
     __builtin_amdgcn_sched_barrier(0);
     for (int ch = 0; ch < nch; ch += 2) {
         FD_CHUNK(ch, resA, resB);
@@ -1310,6 +1339,378 @@ int conv_tail_fused_forward(const SplitConvParams& p2, const SplitConvParams& p3
                         4.0 * a.M * s3.cout * ((c.res ? 1.0 : 0.0) + (c.y32 ? 1.0 : 0.0) + (c.ysplit ? 1.0 : 0.0)));
     hipLaunchKernelGGL((conv_tail_fused_kernel<128, 64>), dim3(tiles_m), dim3(256), 0, stream, a, c, (unsigned)x_bytes,
                        (unsigned)w_bytes, (unsigned)w3_bytes);
+    FD_LAUNCH_CHECK();
+    *taken = true;
+    return FD_OK;
+}
+
+// ---------------------------------------------------------------------------------
+// A whole identity-shortcut bottleneck unit of the 64-channel stage in one kernel:
+//   t1 = relu(conv1x1(relu(bn1(x))) + b1)   (256 -> 64, BatchNorm bn2 folded into the weights)
+//   t2 = relu(conv3x3(t1) + b2)             (64 -> 64, bn3 folded)
+//   y  = conv1x1(t2) + x                    (64 -> 256)
+// A workgroup owns an 8 x 16 pixel tile of one image.  It computes t1 on the tile's 10 x 18 halo
+// patch straight from the float32 input (BatchNorm+ReLU+split between the global load and the MFMA
+// operand registers), keeps t1 in LDS as a split image, runs the 3x3 out of that image, keeps t2 in
+// LDS as the last convolution's operand and finishes like conv_tail_fused_kernel.  Neither t1 nor
+// t2 goes to HBM, and x is read from HBM once (the residual read at the end hits the caches).
+//
+// In the first two phases the weights are the MFMA's row operand and the pixels its column
+// operand, so a lane ends up with 4 consecutive channels of one pixel: 8 bytes of hi and 8 bytes
+// of lo halves that go straight into the LDS image without a transpose.
+//
+// LDS, phases 0-1: [t1 patch: 2 K-step planes x 192 rows x 128 B | 2 weight stages x 8 KB |
+//                   bn1 scale and shift 2 KB]
+//      phases 2-3: [epilogue staging 20 KB | t2 operand 32 KB | weight chunk 16 KB]
+struct UnitFusedArgs {
+    SplitKArgs c1, c2, c3;      // c1.x: float32 input; c3.res: the same tensor; c3.y32 / c3.ysplit: outputs
+    unsigned x_bytes, w1_bytes, w2_bytes, w3_bytes;
+    int tiles_x, tiles_y;
+};
+
+__global__ __launch_bounds__(256, 2) void unit_fused_kernel(UnitFusedArgs u) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    constexpr int BM = 128, MID = 64, BN = 64, CIN = 256;
+    using T = SplitTile<BM, BN>;
+    using E = SplitEpi<BM, BN>;
+    constexpr int PW = 18, PPIX = 180, PROWS = 192;        // patch width, pixels, rows incl. padding
+    constexpr int PLANE = PROWS * 128;                     // bytes per K-step plane of the patch
+    constexpr int WST_OFF = 2 * PLANE, WSTAGE = 64 * 128;  // weight stages of phases 0 and 1
+    constexpr int PS_OFF = WST_OFF + 2 * WSTAGE;           // bn1 scale [256], shift [256]
+    constexpr int CS_BYTES = 20 * 1024;
+    constexpr int AIMG_BYTES = (MID / 32) * BM * 128;
+    constexpr int WCH_BYTES = (MID / 32) * 64 * 128;
+    constexpr int SMEM_BYTES = CS_BYTES + AIMG_BYTES + WCH_BYTES;
+    static_assert(PS_OFF + 2 * CIN * 4 <= SMEM_BYTES && T::EPI * 4 <= CS_BYTES && SMEM_BYTES <= 80 * 1024, "LDS plan");
+    __shared__ __attribute__((aligned(16))) float smem[SMEM_BYTES / 4];
+    char* const sbytes = reinterpret_cast<char*>(smem);
+
+    const SplitKArgs &a1 = u.c1, &a2 = u.c2, &c = u.c3;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    int wgid;
+    {
+        const int nwg = gridDim.x, bid = blockIdx.x;
+        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+        wgid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    }
+    const int H = a1.H, W = a1.W;
+    const int per_img = u.tiles_x * u.tiles_y;
+    const int img = wgid / per_img;
+    const int trem = wgid - img * per_img;
+    const int tyi = trem / u.tiles_x, txi = trem - tyi * u.tiles_x;
+    const int y0 = tyi * 8, x0 = txi * 16;
+
+    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)a1.x, 0, u.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t w1r = __builtin_amdgcn_make_buffer_rsrc((void*)a1.w, 0, u.w1_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t w2r = __builtin_amdgcn_make_buffer_rsrc((void*)a2.w, 0, u.w2_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t w3r = __builtin_amdgcn_make_buffer_rsrc((void*)c.w, 0, u.w3_bytes, 0x00020000);
+    constexpr unsigned OOB = 0x80000000u;
+
+    const int frow = lane & 15, fh = lane >> 4;
+    const int sw = (frow >> 1) & 7;
+    const int lrow = lane >> 3, lpos = lane & 7;
+
+    // bn1 scale and shift into LDS
+    if (tid < 64) *reinterpret_cast<f32x4*>(sbytes + PS_OFF + tid * 16) = *reinterpret_cast<const f32x4*>(a1.pre_scale + tid * 4);
+    else if (tid < 128)
+        *reinterpret_cast<f32x4*>(sbytes + PS_OFF + CIN * 4 + (tid - 64) * 16) =
+            *reinterpret_cast<const f32x4*>(a1.pre_shift + (tid - 64) * 4);
+
+    // weight rows this lane moves by LDS-DMA in phases 0 and 1 (64 rows per K-step: 2 pieces per wave)
+    unsigned wvo1[2], wvo2[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int row = (wave + 4 * i) * 8 + lrow;
+        const unsigned chunk = (unsigned)((lpos ^ ((row >> 1) & 7)) * 16);
+        wvo1[i] = (unsigned)(row * CIN * 4) + chunk;
+        wvo2[i] = (unsigned)(row * (9 * MID) * 4) + chunk;
+    }
+#define FD_WDMA(RSRC, VO, KT, STG)                                                                \
+    do {                                                                                          \
+        _Pragma("unroll") for (int i = 0; i < 2; ++i)                                             \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(                                             \
+                RSRC, (__attribute__((address_space(3))) void*)(sbytes + WST_OFF + (STG) * WSTAGE + (wave + 4 * i) * 1024), \
+                16, VO[i], (KT) * 128, 0, 0);                                                     \
+    } while (0)
+    // weight fragment of 16 rows NF*16.. of stage STG, part 0: hi, part 1: lo
+    int w_off[2];
+#pragma unroll
+    for (int part = 0; part < 2; ++part) w_off[part] = WST_OFF + frow * 128 + (((part * 4 + fh) ^ sw) * 16);
+
+    // ---- phase 0: t1 on the halo patch; wave w owns patch rows 48 w .. 48 w + 47 ----
+    unsigned xvo[3];
+    bool pval[3];
+#pragma unroll
+    for (int f = 0; f < 3; ++f) {
+        const int pp = (wave * 3 + f) * 16 + frow;
+        const int py = pp / PW, px = pp - py * PW;
+        const int gy = y0 - 1 + py, gx = x0 - 1 + px;
+        pval[f] = pp < PPIX && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
+        xvo[f] = pval[f] ? (unsigned)(((img * H + gy) * W + gx) * (CIN * 4) + fh * 32) : OOB;
+    }
+    f32x4 ra[3][2];
+#define FD_XLOAD(KT)                                                                              \
+    do {                                                                                          \
+        _Pragma("unroll") for (int f = 0; f < 3; ++f) {                                           \
+            ra[f][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xr, xvo[f], (KT) * 128, 0)); \
+            ra[f][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xr, xvo[f] + 16u, (KT) * 128, 0)); \
+        }                                                                                         \
+    } while (0)
+    f32x4 acc0[4][3];
+#pragma unroll
+    for (int nf = 0; nf < 4; ++nf)
+#pragma unroll
+        for (int f = 0; f < 3; ++f) acc0[nf][f] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    FD_WDMA(w1r, wvo1, 0, 0);
+    FD_XLOAD(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+#pragma unroll 1
+    for (int kt = 0; kt < CIN / 32; ++kt) {
+        const int cur = kt & 1;
+        // operand registers of this K-step from the raw values: relu(x * scale + shift), split
+        f16x8 bh[3], bl[3];
+        {
+            const char* ps = sbytes + PS_OFF + (kt * 32 + fh * 8) * 4;
+            const f32x4 s0 = *reinterpret_cast<const f32x4*>(ps), s1 = *reinterpret_cast<const f32x4*>(ps + 16);
+            const f32x4 t0 = *reinterpret_cast<const f32x4*>(ps + CIN * 4), t1 = *reinterpret_cast<const f32x4*>(ps + CIN * 4 + 16);
+#pragma unroll
+            for (int f = 0; f < 3; ++f)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    _Float16 h_, l_;
+                    split_f32_relu(ra[f][0][j] * s0[j] + t0[j], h_, l_);
+                    bh[f][j] = h_; bl[f][j] = l_;
+                    split_f32_relu(ra[f][1][j] * s1[j] + t1[j], h_, l_);
+                    bh[f][4 + j] = h_; bl[f][4 + j] = l_;
+                }
+        }
+        const bool more = kt + 1 < CIN / 32;
+        if (more) {
+            FD_WDMA(w1r, wvo1, kt + 1, cur ^ 1);
+            asm volatile("" ::: "memory");
+            FD_XLOAD(kt + 1);
+            asm volatile("" ::: "memory");
+        }
+        f16x8 ah[4], al[4];
+#pragma unroll
+        for (int nf = 0; nf < 4; ++nf) {
+            ah[nf] = *reinterpret_cast<const f16x8*>(sbytes + w_off[0] + cur * WSTAGE + nf * 2048);
+            al[nf] = *reinterpret_cast<const f16x8*>(sbytes + w_off[1] + cur * WSTAGE + nf * 2048);
+        }
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int nf = 0; nf < 4; ++nf)
+#pragma unroll
+            for (int f = 0; f < 3; ++f) {
+                acc0[nf][f] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[nf], bh[f], acc0[nf][f], 0, 0, 0);
+                acc0[nf][f] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[nf], bl[f], acc0[nf][f], 0, 0, 0);
+                acc0[nf][f] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[nf], bh[f], acc0[nf][f], 0, 0, 0);
+            }
+        __builtin_amdgcn_s_setprio(0);
+        // the weights of the next K-step have landed once only the 6 younger loads are in flight
+        if (more) wait_vmcnt<6>();
+        pipeline_barrier();
+    }
+#undef FD_XLOAD
+    // first weights of the 3x3 while t1 is written out (stage 0 was last read two barriers ago)
+    FD_WDMA(w2r, wvo2, 0, 0);
+    {
+        // a lane holds channels nf * 16 + fh * 4 + j of patch row (3 wave + f) * 16 + frow
+#pragma unroll
+        for (int nf = 0; nf < 4; ++nf) {
+            const f32x4 b = a1.bias ? *reinterpret_cast<const f32x4*>(a1.bias + nf * 16 + fh * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int f = 0; f < 3; ++f) {
+                const int pp = (wave * 3 + f) * 16 + frow;
+                f16x4 h4, l4;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float v = acc0[nf][f][j] * a1.w_inv_scale + b[j];
+                    if (!pval[f]) v = 0.f;                  // zero padding of the 3x3 applies to t1
+                    _Float16 h_, l_;
+                    split_f32_relu(v, h_, l_);
+                    h4[j] = h_; l4[j] = l_;
+                }
+                const int chunk = (nf & 1) * 2 + (fh >> 1);
+                const int off = (nf >> 1) * PLANE + pp * 128 + ((chunk ^ ((pp >> 1) & 7)) * 16) + (fh & 1) * 8;
+                *reinterpret_cast<f16x4*>(sbytes + off) = h4;
+                *reinterpret_cast<f16x4*>(sbytes + (off ^ 64)) = l4;
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    // ---- phase 1: the 3x3 out of the patch; wave w owns tile rows 2 w and 2 w + 1 ----
+    f32x4 acc1[4][2];
+#pragma unroll
+    for (int nf = 0; nf < 4; ++nf)
+#pragma unroll
+        for (int pf = 0; pf < 2; ++pf) acc1[nf][pf] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+        const int dy = tap / 3, dx = tap - dy * 3;
+        int p_off[2][2];
+#pragma unroll
+        for (int pf = 0; pf < 2; ++pf) {
+            const int pp = (2 * wave + pf + dy) * PW + frow + dx;
+            const int sp = (pp >> 1) & 7;
+#pragma unroll
+            for (int part = 0; part < 2; ++part) p_off[pf][part] = pp * 128 + (((part * 4 + fh) ^ sp) * 16);
+        }
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            const int kt = tap * 2 + kk, cur = kt & 1;
+            if (kt + 1 < 18) FD_WDMA(w2r, wvo2, kt + 1, cur ^ 1);
+            f16x8 ah[4], al[4], bh[2], bl[2];
+#pragma unroll
+            for (int nf = 0; nf < 4; ++nf) {
+                ah[nf] = *reinterpret_cast<const f16x8*>(sbytes + w_off[0] + cur * WSTAGE + nf * 2048);
+                al[nf] = *reinterpret_cast<const f16x8*>(sbytes + w_off[1] + cur * WSTAGE + nf * 2048);
+            }
+#pragma unroll
+            for (int pf = 0; pf < 2; ++pf) {
+                bh[pf] = *reinterpret_cast<const f16x8*>(sbytes + kk * PLANE + p_off[pf][0]);
+                bl[pf] = *reinterpret_cast<const f16x8*>(sbytes + kk * PLANE + p_off[pf][1]);
+            }
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int nf = 0; nf < 4; ++nf)
+#pragma unroll
+                for (int pf = 0; pf < 2; ++pf) {
+                    acc1[nf][pf] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[nf], bh[pf], acc1[nf][pf], 0, 0, 0);
+                    acc1[nf][pf] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[nf], bl[pf], acc1[nf][pf], 0, 0, 0);
+                    acc1[nf][pf] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[nf], bh[pf], acc1[nf][pf], 0, 0, 0);
+                }
+            __builtin_amdgcn_s_setprio(0);
+            wait_vmcnt<0>();
+            pipeline_barrier();
+        }
+    }
+#undef FD_WDMA
+
+    // ---- phase 2: t2 = relu(. + b2), split, into the last convolution's operand image ----
+    // (the patch and the weight stages are dead: every wave has passed the last barrier)
+    float* wch = smem + (CS_BYTES + AIMG_BYTES) / 4;
+#define FD_WEIGHTS(CH)                                                                            \
+    do {                                                                                          \
+        _Pragma("unroll") for (int kk = 0; kk < MID / 32; ++kk)                                   \
+            _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                       \
+                const int row = (wave + 4 * i) * 8 + lrow;                                        \
+                const unsigned vo = (unsigned)((((CH) * 64 + row) * MID + kk * 32) * 4 + (lpos ^ ((row >> 1) & 7)) * 16); \
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(                                         \
+                    w3r, (__attribute__((address_space(3))) void*)(wch + kk * (64 * 32) + (wave + 4 * i) * 256), 16, vo, \
+                    0, 0, 0);                                                                     \
+            }                                                                                     \
+    } while (0)
+    const PatchRows rows{(img * H + y0) * W + x0, W, H - y0, W - x0};
+    constexpr int RL = E::GROUPS * E::PASSES * 2;        // residual loads per chunk and lane
+    f32x4 resA[E::GROUPS][E::PASSES][2], resB[E::GROUPS][E::PASSES][2];
+    FD_WEIGHTS(0);
+    split_residual_prefetch<BM, BN>(c, rows, 0, wave, lane, resA);
+    __builtin_amdgcn_sched_barrier(0);
+    {
+#pragma unroll
+        for (int nf = 0; nf < 4; ++nf) {
+            const f32x4 b = a2.bias ? *reinterpret_cast<const f32x4*>(a2.bias + nf * 16 + fh * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int pf = 0; pf < 2; ++pf) {
+                const int row = (2 * wave + pf) * 16 + frow;
+                f16x4 h4, l4;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    _Float16 h_, l_;
+                    split_f32_relu(acc1[nf][pf][j] * a2.w_inv_scale + b[j], h_, l_);
+                    h4[j] = h_; l4[j] = l_;
+                }
+                const int chunk = (nf & 1) * 2 + (fh >> 1);
+                const int off = CS_BYTES + (nf >> 1) * (BM * 128) + row * 128 + ((chunk ^ ((row >> 1) & 7)) * 16) + (fh & 1) * 8;
+                *reinterpret_cast<f16x4*>(sbytes + off) = h4;
+                *reinterpret_cast<f16x4*>(sbytes + (off ^ 64)) = l4;
+            }
+        }
+    }
+
+    // ---- phase 3: the last 1x1 convolution, 64 output channels at a time (as conv_tail_fused_kernel) ----
+    const char* sbase = sbytes;
+    int a3_off[MID / 32][2], b3_off[MID / 32][2];
+#pragma unroll
+    for (int kk = 0; kk < MID / 32; ++kk)
+#pragma unroll
+        for (int part = 0; part < 2; ++part) {
+            const int pos = ((part * 4 + fh) ^ sw) * 16;
+            a3_off[kk][part] = CS_BYTES + kk * (BM * 128) + (wm * (BM / 2) + frow) * 128 + pos;
+            b3_off[kk][part] = CS_BYTES + AIMG_BYTES + kk * (64 * 128) + (wn * 32 + frow) * 128 + pos;
+        }
+#define FD_CHUNK(CH, RCUR, RNEXT)                                                                 \
+    do {                                                                                          \
+        wait_vmcnt<RL>();              /* weights of this chunk landed; its residual may fly */   \
+        __syncthreads();               /* ... for every wave; first chunk: operand image complete */ \
+        f32x4 acc3[T::AM][T::AN];                                                                 \
+        _Pragma("unroll") for (int mi = 0; mi < T::AM; ++mi)                                      \
+            _Pragma("unroll") for (int ni = 0; ni < T::AN; ++ni) acc3[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f}; \
+        _Pragma("unroll") for (int kk = 0; kk < MID / 32; ++kk)                                   \
+            split_mma_step<BM, BN>(sbase, a3_off[kk], b3_off[kk], acc3);                          \
+        __syncthreads();               /* every wave is done reading the weight chunk */          \
+        if ((CH) + 1 < nch) {                                                                     \
+            FD_WEIGHTS((CH) + 1);                                                                 \
+            split_residual_prefetch<BM, BN>(c, rows, (CH) + 1, wave, lane, RNEXT);                \
+            __builtin_amdgcn_sched_barrier(0);                                                    \
+        }                                                                                         \
+        split_epilogue16_rows<BM, BN, true>(c, smem, rows, (CH), wave, lane, acc3, RCUR);         \
+    } while (0)
+    const int nch = c.Cout / 64;
+    for (int ch = 0; ch < nch; ch += 2) {
+        FD_CHUNK(ch, resA, resB);
+        if (ch + 1 < nch) FD_CHUNK(ch + 1, resB, resA);
+    }
+#undef FD_CHUNK
+#undef FD_WEIGHTS
+#endif
+}
+
+int unit_fused_forward(const SplitConvParams& p1, const SplitConvParams& p2, const SplitConvParams& p3, const float* x32,
+                       const float* pre_scale, const float* pre_shift, int batch, int h, int w, const SplitConvOut& out,
+                       hipStream_t stream, bool* taken) {
+    *taken = false;
+    const ConvShape &s1 = p1.s, &s2 = p2.s, &s3 = p3.s;
+    if (!(s1.cin == 256 && s1.cout == 64 && s1.kh == 1 && s1.kw == 1 && s1.stride == 1 && s1.pad == 0 && p1.relu &&
+          s2.cin == 64 && s2.cout == 64 && s2.kh == 3 && s2.kw == 3 && s2.kwp == 3 && s2.stride == 1 && s2.pad == 1 &&
+          p2.relu && s3.cin == 64 && s3.cout == 256 && s3.kh == 1 && s3.kw == 1 && s3.stride == 1 && s3.pad == 0))
+        return FD_OK;
+    const long long m_ll = (long long)batch * h * w;
+    const size_t x_bytes = (size_t)m_ll * 256 * 4;
+    if (x_bytes >= (1ull << 31)) return FD_OK;
+    FD_REQUIRE(x32 && pre_scale && pre_shift && p1.w && p2.w && p3.w && (out.y32 || out.ysplit), "fused unit: NULL tensor");
+    UnitFusedArgs u;
+    SplitKArgs a;
+    a.x = reinterpret_cast<const uint8_t*>(x32); a.w = static_cast<const uint8_t*>(p1.w);
+    a.bias = p1.bias; a.res = nullptr; a.y32 = nullptr; a.ysplit = nullptr; a.post_scale = a.post_shift = nullptr;
+    a.pre_scale = pre_scale; a.pre_shift = pre_shift; a.w_inv_scale = p1.w_inv_scale;
+    a.H = h; a.W = w; a.Cin = 256; a.Ho = h; a.Wo = w; a.Cout = 64; a.KW = 1; a.stride = 1; a.pad = 0; a.K = 256;
+    a.M = (int)m_ll; a.relu = 1; a.tiles_n = 1; a.ksplit = 1; a.kchunk = a.K / SBK; a.partial = nullptr;
+    u.c1 = a;
+    u.c2 = a;
+    u.c2.x = nullptr; u.c2.w = static_cast<const uint8_t*>(p2.w); u.c2.bias = p2.bias; u.c2.pre_scale = u.c2.pre_shift = nullptr;
+    u.c2.w_inv_scale = p2.w_inv_scale; u.c2.Cin = 64; u.c2.KW = 3; u.c2.pad = 1; u.c2.K = 576; u.c2.kchunk = 18;
+    u.c3 = a;
+    u.c3.x = nullptr; u.c3.w = static_cast<const uint8_t*>(p3.w); u.c3.bias = p3.bias; u.c3.res = x32; u.c3.y32 = out.y32;
+    u.c3.ysplit = static_cast<uint8_t*>(out.ysplit); u.c3.post_scale = out.post_scale; u.c3.post_shift = out.post_shift;
+    u.c3.pre_scale = u.c3.pre_shift = nullptr; u.c3.w_inv_scale = p3.w_inv_scale; u.c3.Cin = 64; u.c3.Cout = 256; u.c3.K = 64;
+    u.c3.kchunk = 2; u.c3.relu = p3.relu; u.c3.tiles_n = 4;
+    u.x_bytes = (unsigned)x_bytes;
+    u.w1_bytes = (unsigned)(s1.packed_floats() * 4); u.w2_bytes = (unsigned)(s2.packed_floats() * 4);
+    u.w3_bytes = (unsigned)(s3.packed_floats() * 4);
+    u.tiles_x = ceil_div(w, 16); u.tiles_y = ceil_div(h, 8);
+    const long long wgs = (long long)batch * u.tiles_x * u.tiles_y;
+    if (wgs >= (1ll << 31)) return FD_OK;
+    const double M = (double)m_ll;
+    ProfScope scope(stream, "unit_fused", 2.0 * M * 64.0 * (256.0 + 576.0 + 256.0),
+                    4.0 * M * 256.0 * ((out.y32 ? 2.0 : 1.0) + (out.ysplit ? 1.0 : 0.0)) + 4.0 * 64.0 * (256.0 + 576.0 + 256.0));
+    hipLaunchKernelGGL(unit_fused_kernel, dim3((unsigned)wgs), dim3(256), 0, stream, u);
     FD_LAUNCH_CHECK();
     *taken = true;
     return FD_OK;

@@ -7,6 +7,7 @@
 #include "fd_conv_split.h"
 
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -55,6 +56,7 @@ struct fd_detector {
     std::vector<fd::Tap> taps;
     fd::Buf net[fd::NB_COUNT];
     bool keep_taps = false;              // debugging: snapshot every tapped tensor
+    bool fuse_units = true;              // whole-unit kernel for the 64-channel identity units (FD_FUSE_UNITS=0 turns it off)
     std::vector<void*> tap_copies;
 };
 
@@ -451,17 +453,26 @@ static int run_unit_split(Plan& pl, const Unit& u, const char* name, const void*
         o3.ysplit = ysplit;
         o3.post_scale = next_scale;
         o3.post_shift = next_shift;
-        if (u.has_sc) {
-            FD_TRY(split_conv_forward(u.s_conv1, act, n, h, w, nullptr, o1, pl.stream));
-        } else {
-            FD_TRY(split_conv_forward_f32(u.s_conv1, xraw, u.bn1_scale, u.bn1_shift, n, h, w, nullptr, o1,
-                                          pl.stream));
-        }
-        bool fused = false;
-        if (!pl.d->keep_taps) FD_TRY(conv_tail_fused_forward(u.s_conv2, u.s_conv3, t1, n, h, w, res, o3, pl.stream, &fused));
-        if (!fused) {
-            FD_TRY(split_conv_forward(u.s_conv2, t1, n, h, w, nullptr, o2, pl.stream));
-            FD_TRY(split_conv_forward(u.s_conv3, t2, n, ho, wo, res, o3, pl.stream));
+        // identity units of the 64-channel stage run as one kernel (nothing between the unit's
+        // input and output goes to HBM); the intermediate tensors exist only for inspection
+        bool whole = false;
+        if (!u.has_sc && !pl.d->keep_taps && pl.d->fuse_units)
+            FD_TRY(unit_fused_forward(u.s_conv1, u.s_conv2, u.s_conv3, xraw, u.bn1_scale, u.bn1_shift, n, h, w, o3,
+                                      pl.stream, &whole));
+        if (!whole) {
+            if (u.has_sc) {
+                FD_TRY(split_conv_forward(u.s_conv1, act, n, h, w, nullptr, o1, pl.stream));
+            } else {
+                FD_TRY(split_conv_forward_f32(u.s_conv1, xraw, u.bn1_scale, u.bn1_shift, n, h, w, nullptr, o1,
+                                              pl.stream));
+            }
+            bool fused = false;
+            if (!pl.d->keep_taps)
+                FD_TRY(conv_tail_fused_forward(u.s_conv2, u.s_conv3, t1, n, h, w, res, o3, pl.stream, &fused));
+            if (!fused) {
+                FD_TRY(split_conv_forward(u.s_conv2, t1, n, h, w, nullptr, o2, pl.stream));
+                FD_TRY(split_conv_forward(u.s_conv3, t2, n, ho, wo, res, o3, pl.stream));
+            }
         }
     }
     if (y32) pl.tap(name, y32, n, ho, wo, cout);
@@ -683,6 +694,7 @@ int fd_detector_create(fd_ctx* ctx, const fd_param* params, int n_params, const 
         if (params[i].name) t.m[params[i].name] = &params[i];
     fd_detector* d = new fd_detector();
     d->ctx = ctx;
+    if (const char* e = getenv("FD_FUSE_UNITS")) d->fuse_units = atoi(e) != 0;
     d->prop = *cfg;
     const int rc = fd::build(d, t);
     if (rc != FD_OK) {
