@@ -47,6 +47,12 @@ int unit_fused_forward(const SplitConvParams& conv1, const SplitConvParams& conv
                        const float* x32, const float* pre_scale, const float* pre_shift, int batch, int h, int w,
                        const SplitConvOut& out, hipStream_t stream, bool* taken);
 
+// The projection-shortcut unit of the 64-channel stage (conv1, conv2, conv3 and the shortcut
+// convolution, all on the split input act) in one kernel writing the float32 sum; *taken as above.
+int unit_proj_fused_forward(const SplitConvParams& conv1, const SplitConvParams& conv2, const SplitConvParams& conv3,
+                            const SplitConvParams& shortcut, const void* act_split, int batch, int h, int w, float* y32,
+                            hipStream_t stream, bool* taken);
+
 // float32 [rows][channels] -> split, optionally through relu(x * scale[c] + shift[c]).
 int to_split(const float* x, long long rows, int channels, const float* scale, const float* shift, void* y,
              hipStream_t stream);

@@ -1716,6 +1716,382 @@ int unit_fused_forward(const SplitConvParams& p1, const SplitConvParams& p2, con
     return FD_OK;
 }
 
+// ---------------------------------------------------------------------------------
+// The projection-shortcut unit of the 64-channel stage (first unit after the max-pool) in one
+// kernel.  Input: act = split(relu(bn1(x))) with 64 channels.
+//   t1 = relu(conv1x1(act) + b1),  t2 = relu(conv3x3(t1) + b2),  y = conv1x1(t2) + conv1x1_sc(act)
+// Same 8 x 16 pixel tiles and 10 x 18 halo patch as unit_fused_kernel.  The patch of act arrives by
+// LDS-DMA; each wave turns its own 48 patch rows into t1 in place (the first convolution is
+// pointwise), the 3x3 runs out of that image, and the last phase accumulates the main branch and
+// the shortcut convolution for 64 output channels at a time -- the shortcut tensor is never
+// written, so the unit reads act and writes y and nothing else.  The tile's own act pixels are
+// fetched a second time for that (the patch was overwritten by t1).  The output leaves the
+// accumulators directly: with the weights as the MFMA's row operand a lane owns 4 consecutive
+// channels of a pixel, one 16-byte store.
+//
+// LDS, phases 0-1: [patch: 2 K-step planes x 192 rows x 128 B | 2 weight stages x 8 KB]
+//      phases 2-3: [t2 operand 32 KB | act operand 32 KB | 2 weight stages x 8 KB]
+struct UnitProjArgs {
+    SplitKArgs c1, c2, c3, sc;  // c1.x: act (split); c3.y32: output
+    unsigned x_bytes, w1_bytes, w2_bytes, w3_bytes, wsc_bytes;
+    int tiles_x, tiles_y;
+};
+
+__global__ __launch_bounds__(256, 2) void unit_proj_fused_kernel(UnitProjArgs u) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    constexpr int BM = 128, MID = 64;
+    constexpr int PW = 18, PPIX = 180, PROWS = 192;
+    constexpr int PLANE = PROWS * 128;
+    constexpr int WST_OFF = 2 * PLANE, WSTAGE = 64 * 128;
+    constexpr int T2_OFF = 0, ACT_OFF = 2 * BM * 128, W3_OFF = 4 * BM * 128;
+    constexpr int SMEM_BYTES = W3_OFF + 2 * WSTAGE;
+    static_assert(WST_OFF + 2 * WSTAGE <= W3_OFF && SMEM_BYTES <= 80 * 1024, "LDS plan");
+    __shared__ __attribute__((aligned(16))) float smem[SMEM_BYTES / 4];
+    char* const sbytes = reinterpret_cast<char*>(smem);
+
+    const SplitKArgs &a1 = u.c1, &a2 = u.c2, &c = u.c3;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int wgid;
+    {
+        const int nwg = gridDim.x, bid = blockIdx.x;
+        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+        wgid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    }
+    const int H = a1.H, W = a1.W;
+    const int per_img = u.tiles_x * u.tiles_y;
+    const int img = wgid / per_img;
+    const int trem = wgid - img * per_img;
+    const int tyi = trem / u.tiles_x, txi = trem - tyi * u.tiles_x;
+    const int y0 = tyi * 8, x0 = txi * 16;
+
+    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)a1.x, 0, u.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t w1r = __builtin_amdgcn_make_buffer_rsrc((void*)a1.w, 0, u.w1_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t w2r = __builtin_amdgcn_make_buffer_rsrc((void*)a2.w, 0, u.w2_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t w3r = __builtin_amdgcn_make_buffer_rsrc((void*)c.w, 0, u.w3_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t wsr = __builtin_amdgcn_make_buffer_rsrc((void*)u.sc.w, 0, u.wsc_bytes, 0x00020000);
+    constexpr unsigned OOB = 0x80000000u;
+
+    const int frow = lane & 15, fh = lane >> 4;
+    const int sw = (frow >> 1) & 7;
+    const int lrow = lane >> 3, lpos = lane & 7;
+
+    // ---- phase 0: the act patch by LDS-DMA (each wave its own 48 rows), then t1 in place ----
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        const int pp = wave * 48 + i * 8 + lrow;
+        const int py = pp / PW, px = pp - py * PW;
+        const int gy = y0 - 1 + py, gx = x0 - 1 + px;
+        const bool ok = pp < PPIX && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
+        const unsigned vo = ok ? (unsigned)(((img * H + gy) * W + gx) * (MID * 4) + (lpos ^ ((pp >> 1) & 7)) * 16) : OOB;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(
+                xr, (__attribute__((address_space(3))) void*)(sbytes + kk * PLANE + (wave * 48 + i * 8) * 128), 16, vo,
+                kk * 128, 0, 0);
+    }
+    // 64-row weight blocks by LDS-DMA: 2 pieces per wave
+    unsigned wvo1[2], wvo2[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int row = (wave + 4 * i) * 8 + lrow;
+        const unsigned chunk = (unsigned)((lpos ^ ((row >> 1) & 7)) * 16);
+        wvo1[i] = (unsigned)(row * MID * 4) + chunk;          // conv1, conv3 and the shortcut: K = 64
+        wvo2[i] = (unsigned)(row * (9 * MID) * 4) + chunk;    // conv2: K = 576
+    }
+#define FD_WDMA(RSRC, VO, ROWOFF, KT, DST)                                                        \
+    do {                                                                                          \
+        _Pragma("unroll") for (int i = 0; i < 2; ++i)                                             \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(                                             \
+                RSRC, (__attribute__((address_space(3))) void*)(sbytes + (DST) + (wave + 4 * i) * 1024), 16,       \
+                VO[i] + (unsigned)(ROWOFF), (KT) * 128, 0, 0);                                    \
+    } while (0)
+    FD_WDMA(w1r, wvo1, 0, 0, WST_OFF);
+    FD_WDMA(w1r, wvo1, 0, 1, WST_OFF + WSTAGE);
+    int w_off[2];
+#pragma unroll
+    for (int part = 0; part < 2; ++part) w_off[part] = frow * 128 + (((part * 4 + fh) ^ sw) * 16);
+    bool pval[3];
+    int prow_off[3][2];
+#pragma unroll
+    for (int f = 0; f < 3; ++f) {
+        const int pp = (wave * 3 + f) * 16 + frow;
+        const int py = pp / PW, px = pp - py * PW;
+        const int gy = y0 - 1 + py, gx = x0 - 1 + px;
+        pval[f] = pp < PPIX && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
+#pragma unroll
+        for (int part = 0; part < 2; ++part) prow_off[f][part] = pp * 128 + (((part * 4 + fh) ^ ((pp >> 1) & 7)) * 16);
+    }
+    wait_vmcnt<0>();
+    __syncthreads();
+    f32x4 acc0[4][3];
+#pragma unroll
+    for (int nf = 0; nf < 4; ++nf)
+#pragma unroll
+        for (int f = 0; f < 3; ++f) acc0[nf][f] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+        f16x8 ah[4], al[4], bh[3], bl[3];
+#pragma unroll
+        for (int nf = 0; nf < 4; ++nf) {
+            ah[nf] = *reinterpret_cast<const f16x8*>(sbytes + WST_OFF + kk * WSTAGE + w_off[0] + nf * 2048);
+            al[nf] = *reinterpret_cast<const f16x8*>(sbytes + WST_OFF + kk * WSTAGE + w_off[1] + nf * 2048);
+        }
+#pragma unroll
+        for (int f = 0; f < 3; ++f) {
+            bh[f] = *reinterpret_cast<const f16x8*>(sbytes + kk * PLANE + prow_off[f][0]);
+            bl[f] = *reinterpret_cast<const f16x8*>(sbytes + kk * PLANE + prow_off[f][1]);
+        }
+#pragma unroll
+        for (int nf = 0; nf < 4; ++nf)
+#pragma unroll
+            for (int f = 0; f < 3; ++f) {
+                acc0[nf][f] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[nf], bh[f], acc0[nf][f], 0, 0, 0);
+                acc0[nf][f] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[nf], bl[f], acc0[nf][f], 0, 0, 0);
+                acc0[nf][f] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[nf], bh[f], acc0[nf][f], 0, 0, 0);
+            }
+    }
+    __syncthreads();        // every wave has read the conv1 weights (and its own act rows)
+    FD_WDMA(w2r, wvo2, 0, 0, WST_OFF);
+    {
+#pragma unroll
+        for (int nf = 0; nf < 4; ++nf) {
+            const f32x4 b = a1.bias ? *reinterpret_cast<const f32x4*>(a1.bias + nf * 16 + fh * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int f = 0; f < 3; ++f) {
+                const int pp = (wave * 3 + f) * 16 + frow;
+                f16x4 h4, l4;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float v = acc0[nf][f][j] * a1.w_inv_scale + b[j];
+                    if (!pval[f]) v = 0.f;                  // zero padding of the 3x3 applies to t1
+                    _Float16 h_, l_;
+                    split_f32_relu(v, h_, l_);
+                    h4[j] = h_; l4[j] = l_;
+                }
+                const int chunk = (nf & 1) * 2 + (fh >> 1);
+                const int off = (nf >> 1) * PLANE + pp * 128 + ((chunk ^ ((pp >> 1) & 7)) * 16) + (fh & 1) * 8;
+                *reinterpret_cast<f16x4*>(sbytes + off) = h4;
+                *reinterpret_cast<f16x4*>(sbytes + (off ^ 64)) = l4;
+            }
+        }
+    }
+    wait_vmcnt<0>();
+    __syncthreads();
+
+    // ---- phase 1: the 3x3 out of the patch; wave w owns tile rows 2 w and 2 w + 1 ----
+    f32x4 acc1[4][2];
+#pragma unroll
+    for (int nf = 0; nf < 4; ++nf)
+#pragma unroll
+        for (int pf = 0; pf < 2; ++pf) acc1[nf][pf] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+        const int dy = tap / 3, dx = tap - dy * 3;
+        int p_off[2][2];
+#pragma unroll
+        for (int pf = 0; pf < 2; ++pf) {
+            const int pp = (2 * wave + pf + dy) * PW + frow + dx;
+            const int sp = (pp >> 1) & 7;
+#pragma unroll
+            for (int part = 0; part < 2; ++part) p_off[pf][part] = pp * 128 + (((part * 4 + fh) ^ sp) * 16);
+        }
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            const int kt = tap * 2 + kk, cur = kt & 1;
+            if (kt + 1 < 18) FD_WDMA(w2r, wvo2, 0, kt + 1, WST_OFF + (cur ^ 1) * WSTAGE);
+            f16x8 ah[4], al[4], bh[2], bl[2];
+#pragma unroll
+            for (int nf = 0; nf < 4; ++nf) {
+                ah[nf] = *reinterpret_cast<const f16x8*>(sbytes + WST_OFF + cur * WSTAGE + w_off[0] + nf * 2048);
+                al[nf] = *reinterpret_cast<const f16x8*>(sbytes + WST_OFF + cur * WSTAGE + w_off[1] + nf * 2048);
+            }
+#pragma unroll
+            for (int pf = 0; pf < 2; ++pf) {
+                bh[pf] = *reinterpret_cast<const f16x8*>(sbytes + kk * PLANE + p_off[pf][0]);
+                bl[pf] = *reinterpret_cast<const f16x8*>(sbytes + kk * PLANE + p_off[pf][1]);
+            }
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int nf = 0; nf < 4; ++nf)
+#pragma unroll
+                for (int pf = 0; pf < 2; ++pf) {
+                    acc1[nf][pf] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[nf], bh[pf], acc1[nf][pf], 0, 0, 0);
+                    acc1[nf][pf] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[nf], bl[pf], acc1[nf][pf], 0, 0, 0);
+                    acc1[nf][pf] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[nf], bh[pf], acc1[nf][pf], 0, 0, 0);
+                }
+            __builtin_amdgcn_s_setprio(0);
+            wait_vmcnt<0>();
+            pipeline_barrier();
+        }
+    }
+
+    // ---- phase 2: the tile's own act pixels again (operand of the shortcut convolution), the
+    //      first weight block of the last phase, and t2 into its operand image ----
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = (wave * 4 + i) * 8 + lrow;
+        const int gy = y0 + (row >> 4), gx = x0 + (row & 15);
+        const bool ok = gy < H && gx < W;
+        const unsigned vo = ok ? (unsigned)(((img * H + gy) * W + gx) * (MID * 4) + (lpos ^ ((row >> 1) & 7)) * 16) : OOB;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(
+                xr, (__attribute__((address_space(3))) void*)(sbytes + ACT_OFF + kk * (BM * 128) + (wave * 4 + i) * 1024), 16,
+                vo, kk * 128, 0, 0);
+    }
+    FD_WDMA(w3r, wvo1, 0, 0, W3_OFF);
+    {
+#pragma unroll
+        for (int nf = 0; nf < 4; ++nf) {
+            const f32x4 b = a2.bias ? *reinterpret_cast<const f32x4*>(a2.bias + nf * 16 + fh * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int pf = 0; pf < 2; ++pf) {
+                const int row = (2 * wave + pf) * 16 + frow;
+                f16x4 h4, l4;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    _Float16 h_, l_;
+                    split_f32_relu(acc1[nf][pf][j] * a2.w_inv_scale + b[j], h_, l_);
+                    h4[j] = h_; l4[j] = l_;
+                }
+                const int chunk = (nf & 1) * 2 + (fh >> 1);
+                const int off = T2_OFF + (nf >> 1) * (BM * 128) + row * 128 + ((chunk ^ ((row >> 1) & 7)) * 16) + (fh & 1) * 8;
+                *reinterpret_cast<f16x4*>(sbytes + off) = h4;
+                *reinterpret_cast<f16x4*>(sbytes + (off ^ 64)) = l4;
+            }
+        }
+    }
+    wait_vmcnt<0>();
+    __syncthreads();
+
+    // ---- phase 3: y = W3 t2 + Wsc act, 64 output channels at a time; per chunk four K-steps
+    //      (main branch kk 0, 1; shortcut kk 0, 1) through the two weight stages ----
+    int t_off[2][2];            // pixel operand of tile rows (2 wave + pf) * 16 + frow
+#pragma unroll
+    for (int pf = 0; pf < 2; ++pf)
+#pragma unroll
+        for (int part = 0; part < 2; ++part) {
+            const int row = (2 * wave + pf) * 16 + frow;
+            t_off[pf][part] = row * 128 + (((part * 4 + fh) ^ sw) * 16);
+        }
+    const int row_g[2] = {(2 * wave) * 16 + frow, (2 * wave + 1) * 16 + frow};
+    long long out_row[2];
+#pragma unroll
+    for (int pf = 0; pf < 2; ++pf) {
+        const int gy = y0 + 2 * wave + pf, gx = x0 + frow;
+        out_row[pf] = (gy < H && gx < W) ? ((long long)(img * H + gy) * W + gx) : -1;
+    }
+    (void)row_g;
+    const int nch = c.Cout / 64;
+#pragma unroll 1
+    for (int ch = 0; ch < nch; ++ch) {
+        f32x4 accm[4][2], accs[4][2];
+#pragma unroll
+        for (int nf = 0; nf < 4; ++nf)
+#pragma unroll
+            for (int pf = 0; pf < 2; ++pf) { accm[nf][pf] = f32x4{0.f, 0.f, 0.f, 0.f}; accs[nf][pf] = accm[nf][pf]; }
+#pragma unroll
+        for (int st = 0; st < 4; ++st) {
+            const int kk = st & 1, cur = st & 1;
+            // next weight block: st 0 -> main kk 1, st 1 -> shortcut kk 0, st 2 -> shortcut kk 1,
+            // st 3 -> main kk 0 of the next chunk
+            if (st == 0) FD_WDMA(w3r, wvo1, ch * 64 * MID * 4, 1, W3_OFF + WSTAGE);
+            else if (st == 1) FD_WDMA(wsr, wvo1, ch * 64 * MID * 4, 0, W3_OFF);
+            else if (st == 2) FD_WDMA(wsr, wvo1, ch * 64 * MID * 4, 1, W3_OFF + WSTAGE);
+            else if (ch + 1 < nch) FD_WDMA(w3r, wvo1, (ch + 1) * 64 * MID * 4, 0, W3_OFF);
+            f16x8 ah[4], al[4], bh[2], bl[2];
+#pragma unroll
+            for (int nf = 0; nf < 4; ++nf) {
+                ah[nf] = *reinterpret_cast<const f16x8*>(sbytes + W3_OFF + cur * WSTAGE + w_off[0] + nf * 2048);
+                al[nf] = *reinterpret_cast<const f16x8*>(sbytes + W3_OFF + cur * WSTAGE + w_off[1] + nf * 2048);
+            }
+            const int src = (st < 2 ? T2_OFF : ACT_OFF) + kk * (BM * 128);
+#pragma unroll
+            for (int pf = 0; pf < 2; ++pf) {
+                bh[pf] = *reinterpret_cast<const f16x8*>(sbytes + src + t_off[pf][0]);
+                bl[pf] = *reinterpret_cast<const f16x8*>(sbytes + src + t_off[pf][1]);
+            }
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int nf = 0; nf < 4; ++nf)
+#pragma unroll
+                for (int pf = 0; pf < 2; ++pf) {
+                    f32x4& d = st < 2 ? accm[nf][pf] : accs[nf][pf];
+                    d = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[nf], bh[pf], d, 0, 0, 0);
+                    d = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[nf], bl[pf], d, 0, 0, 0);
+                    d = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[nf], bh[pf], d, 0, 0, 0);
+                }
+            __builtin_amdgcn_s_setprio(0);
+            wait_vmcnt<0>();
+            pipeline_barrier();
+        }
+        // a lane holds channels ch * 64 + nf * 16 + fh * 4 + j of tile rows (2 wave + pf) * 16 + frow
+#pragma unroll
+        for (int nf = 0; nf < 4; ++nf) {
+            const int col = ch * 64 + nf * 16 + fh * 4;
+            f32x4 b = {0.f, 0.f, 0.f, 0.f};
+            if (c.bias) b = *reinterpret_cast<const f32x4*>(c.bias + col);
+            if (u.sc.bias) b += *reinterpret_cast<const f32x4*>(u.sc.bias + col);
+#pragma unroll
+            for (int pf = 0; pf < 2; ++pf) {
+                if (out_row[pf] < 0) continue;
+                f32x4 v;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = accm[nf][pf][j] * c.w_inv_scale + (accs[nf][pf][j] * u.sc.w_inv_scale + b[j]);
+                __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(c.y32 + out_row[pf] * c.Cout + col));
+            }
+        }
+    }
+#undef FD_WDMA
+#endif
+}
+
+int unit_proj_fused_forward(const SplitConvParams& p1, const SplitConvParams& p2, const SplitConvParams& p3,
+                            const SplitConvParams& psc, const void* act, int batch, int h, int w, float* y32,
+                            hipStream_t stream, bool* taken) {
+    *taken = false;
+    const ConvShape &s1 = p1.s, &s2 = p2.s, &s3 = p3.s, &ss = psc.s;
+    if (!(s1.cin == 64 && s1.cout == 64 && s1.kh == 1 && s1.kw == 1 && s1.stride == 1 && s1.pad == 0 && p1.relu &&
+          s2.cin == 64 && s2.cout == 64 && s2.kh == 3 && s2.kw == 3 && s2.kwp == 3 && s2.stride == 1 && s2.pad == 1 &&
+          p2.relu && s3.cin == 64 && s3.cout == 256 && s3.kh == 1 && s3.kw == 1 && s3.stride == 1 && s3.pad == 0 &&
+          !p3.relu && ss.cin == 64 && ss.cout == 256 && ss.kh == 1 && ss.kw == 1 && ss.stride == 1 && ss.pad == 0 &&
+          !psc.relu))
+        return FD_OK;
+    const long long m_ll = (long long)batch * h * w;
+    const size_t x_bytes = (size_t)m_ll * 64 * 4;
+    if (x_bytes >= (1ull << 31) || !y32) return FD_OK;
+    FD_REQUIRE(act && p1.w && p2.w && p3.w && psc.w, "fused projection unit: NULL tensor");
+    UnitProjArgs u;
+    SplitKArgs a;
+    a.x = static_cast<const uint8_t*>(act); a.w = static_cast<const uint8_t*>(p1.w);
+    a.bias = p1.bias; a.res = nullptr; a.y32 = nullptr; a.ysplit = nullptr; a.post_scale = a.post_shift = nullptr;
+    a.pre_scale = a.pre_shift = nullptr; a.w_inv_scale = p1.w_inv_scale;
+    a.H = h; a.W = w; a.Cin = 64; a.Ho = h; a.Wo = w; a.Cout = 64; a.KW = 1; a.stride = 1; a.pad = 0; a.K = 64;
+    a.M = (int)m_ll; a.relu = 1; a.tiles_n = 1; a.ksplit = 1; a.kchunk = 2; a.partial = nullptr;
+    u.c1 = a;
+    u.c2 = a;
+    u.c2.x = nullptr; u.c2.w = static_cast<const uint8_t*>(p2.w); u.c2.bias = p2.bias; u.c2.w_inv_scale = p2.w_inv_scale;
+    u.c2.KW = 3; u.c2.pad = 1; u.c2.K = 576; u.c2.kchunk = 18;
+    u.c3 = a;
+    u.c3.x = nullptr; u.c3.w = static_cast<const uint8_t*>(p3.w); u.c3.bias = p3.bias; u.c3.y32 = y32;
+    u.c3.w_inv_scale = p3.w_inv_scale; u.c3.Cout = 256; u.c3.relu = 0; u.c3.tiles_n = 4;
+    u.sc = u.c3;
+    u.sc.w = static_cast<const uint8_t*>(psc.w); u.sc.bias = psc.bias; u.sc.w_inv_scale = psc.w_inv_scale; u.sc.y32 = nullptr;
+    u.x_bytes = (unsigned)x_bytes;
+    u.w1_bytes = (unsigned)(s1.packed_floats() * 4); u.w2_bytes = (unsigned)(s2.packed_floats() * 4);
+    u.w3_bytes = (unsigned)(s3.packed_floats() * 4); u.wsc_bytes = (unsigned)(ss.packed_floats() * 4);
+    u.tiles_x = ceil_div(w, 16); u.tiles_y = ceil_div(h, 8);
+    const long long wgs = (long long)batch * u.tiles_x * u.tiles_y;
+    if (wgs >= (1ll << 31)) return FD_OK;
+    const double M = (double)m_ll;
+    ProfScope scope(stream, "unit_proj_fused", 2.0 * M * 64.0 * (64.0 + 576.0 + 256.0 + 256.0),
+                    4.0 * M * (64.0 + 256.0) + 4.0 * 64.0 * (64.0 + 576.0 + 256.0 + 256.0));
+    hipLaunchKernelGGL(unit_proj_fused_kernel, dim3((unsigned)wgs), dim3(256), 0, stream, u);
+    FD_LAUNCH_CHECK();
+    *taken = true;
+    return FD_OK;
+}
+
 int split_conv_forward(const SplitConvParams& p, const void* x_split, int batch, int h, int w, const float* residual,
                        const SplitConvOut& out, hipStream_t stream) {
     return split_conv_dispatch(p, x_split, nullptr, nullptr, batch, h, w, residual, out, stream);

@@ -436,16 +436,22 @@ static int run_unit_split(Plan& pl, const Unit& u, const char* name, const void*
     float* t1 = pl.buf(NB_T1, (size_t)n * h * w * mid);
     float* t2 = pl.buf(NB_T2, (size_t)n * ho * wo * mid);
     const float* res = xraw;
+    // the projection unit of the 64-channel stage as one kernel: shortcut and main branch are
+    // accumulated together, so neither the shortcut tensor nor t1/t2 exist
+    bool whole_proj = false;
+    if (u.has_sc && !pl.dry && !pl.d->keep_taps && pl.d->fuse_units && y32 && !ysplit)
+        FD_TRY(unit_proj_fused_forward(u.s_conv1, u.s_conv2, u.s_conv3, u.s_sc, act, n, h, w, y32, pl.stream,
+                                       &whole_proj));
     if (u.has_sc) {
         float* s = pl.buf(NB_SC, (size_t)n * ho * wo * cout);
-        if (!pl.dry) {
+        if (!pl.dry && !whole_proj) {
             SplitConvOut o = pl.out();
             o.y32 = s;
             FD_TRY(split_conv_forward(u.s_sc, act, n, h, w, nullptr, o, pl.stream));
         }
         res = s;
     }
-    if (!pl.dry) {
+    if (!pl.dry && !whole_proj) {
         SplitConvOut o1 = pl.out(), o2 = pl.out(), o3 = pl.out();
         o1.ysplit = t1;
         o2.ysplit = t2;

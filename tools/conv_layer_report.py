@@ -5,7 +5,7 @@
 
 Takes the convolution launches of the last complete forward pass in the trace, pairs them with
 the layer list of faster_rcnn50 at 1080p (same order as the library issues them; the stem runs
-fused with the max-pool, conv2+conv3 of the 64-channel units as one kernel) and prints duration
+fused with the max-pool, each unit of the 64-channel stage as one kernel) and prints duration
 and achieved TFLOP/s per layer.  Use a single-stream trace (bench.py --streams 1)."""
 import csv
 import sys
@@ -40,9 +40,10 @@ def layer_list(B, H=1080, W=1920, R=10):
             h2, w2 = conv(nm + "_c2", n, h, w, mid, mid, 3, st, 1)
             conv(nm + "_c3", n, h2, w2, mid, cout, 1, 1, 0)
             if mid == 64 and st == 1:
-                # conv2 and conv3 of the 64-channel bottlenecks run as one fused kernel
-                c3, c2 = layers.pop(), layers.pop()
-                layers.append((nm + "_c2c3", c2[1], c3[2], c2[3], c2[4] + c3[4]))
+                # the units of the 64-channel stage run as one fused kernel each
+                k = 4 if u == 0 else 3
+                parts = [layers.pop() for _ in range(k)]
+                layers.append((nm + "_unit", parts[0][1], parts[0][2], sum(p[3] for p in parts), sum(p[4] for p in parts)))
             h, w, cin = h2, w2, cout
     return layers
 
@@ -51,7 +52,7 @@ def main():
     path = sys.argv[1]
     B = int(sys.argv[2]) if len(sys.argv) > 2 else 8
     rows = [r for r in csv.DictReader(open(path))
-            if any(t in r["Kernel_Name"] for t in ("conv_igemm", "conv_split_", "stem_pool", "conv_tail_fused"))]
+            if any(t in r["Kernel_Name"] for t in ("conv_igemm", "conv_split_", "stem_pool", "conv_tail_fused", "unit_fused", "unit_proj_fused"))]
     layers = layer_list(B)
     last = rows[-len(layers):]
     tot = totf = 0.0
@@ -64,7 +65,8 @@ def main():
         g = groups.setdefault(kind, [0.0, 0.0])
         g[0] += us
         g[1] += L[4]
-        tile = r["Kernel_Name"].split("<")[1].split(">")[0] + (" glds" if "glds" in r["Kernel_Name"] else "")
+        kn = r["Kernel_Name"]
+        tile = (kn.split("<")[1].split(">")[0] if "<" in kn else kn.split("::")[-1].split("(")[0]) + (" glds" if "glds" in kn else "")
         print("%-9s M=%8d N=%5d K=%5d %9.1f us %7.1f TF  tile %s" % (L[0], L[1], L[2], L[3], us, L[4] / us / 1e6, tile))
     print("total %.1f us for %d frames = %.2f ms/frame, %.1f TF" % (tot, B, tot / B / 1e3, totf / tot / 1e6))
     for k, (us, f) in sorted(groups.items(), key=lambda kv: -kv[1][0]):
