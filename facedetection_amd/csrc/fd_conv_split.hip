@@ -10,6 +10,11 @@
 //                             input with BatchNorm+ReLU+split on the way (REG_PRE), or the staged
 //                             4-channel image of the 7x7 stem (REG_STEM); weights by LDS-DMA.
 //   stem_pool_kernel        - the stem fused with the 3x3/2 max-pool (2-D tiles, patch in LDS).
+//   conv_tail_fused_kernel  - 3x3 + following 1x1 of a 64-channel bottleneck (tensor between them in LDS).
+//   unit_fused_kernel       - a whole identity-shortcut unit of the 64-channel stage (8 x 16 pixel
+//                             tiles; both intermediate tensors stay in LDS).
+//   unit_proj_fused_kernel  - the projection-shortcut unit of that stage, shortcut convolution
+//                             accumulated with the main branch.
 //   conv_split_kernel       - pointer-addressed, register-staged form with padded LDS rows and
 //                             32x32x16 blocks; taken only when a tensor exceeds the 2^31-byte
 //                             reach of the buffer-addressed kernels above.
@@ -1380,8 +1385,12 @@ __global__ __launch_bounds__(256, 2) void unit_fused_kernel(UnitFusedArgs u) {
     constexpr int CS_BYTES = 20 * 1024;
     constexpr int AIMG_BYTES = (MID / 32) * BM * 128;
     constexpr int WCH_BYTES = (MID / 32) * 64 * 128;
-    constexpr int SMEM_BYTES = CS_BYTES + AIMG_BYTES + WCH_BYTES;
-    static_assert(PS_OFF + 2 * CIN * 4 <= SMEM_BYTES && T::EPI * 4 <= CS_BYTES && SMEM_BYTES <= 80 * 1024, "LDS plan");
+    constexpr int WBLK = 2 * WSTAGE;                       // phase 1: both K-steps of a filter tap
+    constexpr int WA = WST_OFF, WB = WST_OFF + WBLK;
+    constexpr int SMEM_BYTES = WB + WBLK;
+    static_assert(PS_OFF + 2 * CIN * 4 <= SMEM_BYTES && T::EPI * 4 <= CS_BYTES &&
+                      CS_BYTES + AIMG_BYTES + WCH_BYTES <= SMEM_BYTES && SMEM_BYTES <= 80 * 1024,
+                  "LDS plan");
     __shared__ __attribute__((aligned(16))) float smem[SMEM_BYTES / 4];
     char* const sbytes = reinterpret_cast<char*>(smem);
 
@@ -1515,8 +1524,18 @@ __global__ __launch_bounds__(256, 2) void unit_fused_kernel(UnitFusedArgs u) {
         pipeline_barrier();
     }
 #undef FD_XLOAD
-    // first weights of the 3x3 while t1 is written out (stage 0 was last read two barriers ago)
-    FD_WDMA(w2r, wvo2, 0, 0);
+    // Phase 1 moves its weights in 16 KB blocks (both K-steps of a filter tap); tap t reads block
+    // (t + 1) & 1.  Tap 0 goes out while t1 is written (the scale/shift table and the conv1 stages
+    // are dead: every wave has passed the last barrier of the loop).
+#define FD_WBLOCK(KT0, DST)                                                                       \
+    do {                                                                                          \
+        _Pragma("unroll") for (int kk_ = 0; kk_ < 2; ++kk_)                                       \
+            _Pragma("unroll") for (int i = 0; i < 2; ++i)                                         \
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(                                         \
+                    w2r, (__attribute__((address_space(3))) void*)(sbytes + (DST) + kk_ * WSTAGE + (wave + 4 * i) * 1024), \
+                    16, wvo2[i], ((KT0) + kk_) * 128, 0, 0);                                      \
+    } while (0)
+    FD_WBLOCK(0, WB);
     {
         // a lane holds channels nf * 16 + fh * 4 + j of patch row (3 wave + f) * 16 + frow
 #pragma unroll
@@ -1553,6 +1572,8 @@ __global__ __launch_bounds__(256, 2) void unit_fused_kernel(UnitFusedArgs u) {
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
         const int dy = tap / 3, dx = tap - dy * 3;
+        const int rd = ((tap + 1) & 1) ? WB : WA, wr_ = ((tap + 1) & 1) ? WA : WB;
+        if (tap + 1 < 9) FD_WBLOCK(2 * (tap + 1), wr_);
         int p_off[2][2];
 #pragma unroll
         for (int pf = 0; pf < 2; ++pf) {
@@ -1561,35 +1582,36 @@ __global__ __launch_bounds__(256, 2) void unit_fused_kernel(UnitFusedArgs u) {
 #pragma unroll
             for (int part = 0; part < 2; ++part) p_off[pf][part] = pp * 128 + (((part * 4 + fh) ^ sp) * 16);
         }
+        f16x8 ah[2][4], al[2][4], bh[2][2], bl[2][2];
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
-            const int kt = tap * 2 + kk, cur = kt & 1;
-            if (kt + 1 < 18) FD_WDMA(w2r, wvo2, kt + 1, cur ^ 1);
-            f16x8 ah[4], al[4], bh[2], bl[2];
 #pragma unroll
             for (int nf = 0; nf < 4; ++nf) {
-                ah[nf] = *reinterpret_cast<const f16x8*>(sbytes + w_off[0] + cur * WSTAGE + nf * 2048);
-                al[nf] = *reinterpret_cast<const f16x8*>(sbytes + w_off[1] + cur * WSTAGE + nf * 2048);
+                ah[kk][nf] = *reinterpret_cast<const f16x8*>(sbytes + rd - WST_OFF + kk * WSTAGE + w_off[0] + nf * 2048);
+                al[kk][nf] = *reinterpret_cast<const f16x8*>(sbytes + rd - WST_OFF + kk * WSTAGE + w_off[1] + nf * 2048);
             }
 #pragma unroll
             for (int pf = 0; pf < 2; ++pf) {
-                bh[pf] = *reinterpret_cast<const f16x8*>(sbytes + kk * PLANE + p_off[pf][0]);
-                bl[pf] = *reinterpret_cast<const f16x8*>(sbytes + kk * PLANE + p_off[pf][1]);
+                bh[kk][pf] = *reinterpret_cast<const f16x8*>(sbytes + kk * PLANE + p_off[pf][0]);
+                bl[kk][pf] = *reinterpret_cast<const f16x8*>(sbytes + kk * PLANE + p_off[pf][1]);
             }
-            __builtin_amdgcn_s_setprio(1);
+        }
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
             for (int nf = 0; nf < 4; ++nf)
 #pragma unroll
                 for (int pf = 0; pf < 2; ++pf) {
-                    acc1[nf][pf] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[nf], bh[pf], acc1[nf][pf], 0, 0, 0);
-                    acc1[nf][pf] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[nf], bl[pf], acc1[nf][pf], 0, 0, 0);
-                    acc1[nf][pf] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[nf], bh[pf], acc1[nf][pf], 0, 0, 0);
+                    acc1[nf][pf] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[kk][nf], bh[kk][pf], acc1[nf][pf], 0, 0, 0);
+                    acc1[nf][pf] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[kk][nf], bl[kk][pf], acc1[nf][pf], 0, 0, 0);
+                    acc1[nf][pf] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[kk][nf], bh[kk][pf], acc1[nf][pf], 0, 0, 0);
                 }
-            __builtin_amdgcn_s_setprio(0);
-            wait_vmcnt<0>();
-            pipeline_barrier();
-        }
+        __builtin_amdgcn_s_setprio(0);
+        wait_vmcnt<0>();
+        pipeline_barrier();
     }
+#undef FD_WBLOCK
 #undef FD_WDMA
 
     // ---- phase 2: t2 = relu(. + b2), split, into the last convolution's operand image ----
@@ -1724,16 +1746,19 @@ int unit_fused_forward(const SplitConvParams& p1, const SplitConvParams& p2, con
 // LDS-DMA; each wave turns its own 48 patch rows into t1 in place (the first convolution is
 // pointwise), the 3x3 runs out of that image, and the last phase accumulates the main branch and
 // the shortcut convolution for 64 output channels at a time -- the shortcut tensor is never
-// written, so the unit reads act and writes y and nothing else.  The tile's own act pixels are
-// fetched a second time for that (the patch was overwritten by t1).  The output leaves the
-// accumulators directly: with the weights as the MFMA's row operand a lane owns 4 consecutive
-// channels of a pixel, one 16-byte store.
+// written, so the unit reads act and writes y and nothing else.  The tile's own act pixels (the
+// patch was overwritten by t1) are fetched a second time, straight into the operand registers of
+// the shortcut convolution.  The output leaves the accumulators directly: with the weights as
+// the MFMA's row operand a lane owns 4 consecutive channels of a pixel, one 16-byte store.
 //
-// LDS, phases 0-1: [patch: 2 K-step planes x 192 rows x 128 B | 2 weight stages x 8 KB]
-//      phases 2-3: [t2 operand 32 KB | act operand 32 KB | 2 weight stages x 8 KB]
+// Weights move in 16 KB blocks (64 output channels x 64 K: both K-steps of a filter tap of the
+// 3x3, or of a 64-channel chunk of a 1x1) through LDS-DMA, one block ahead in the 3x3 and two
+// ahead in the last phase.
+// LDS, phases 0-1: [patch: 2 K-step planes x 192 rows x 128 B | 2 weight blocks]
+//      phase 3:    [t2 operand 32 KB | 3 weight blocks]
 struct UnitProjArgs {
     SplitKArgs c1, c2, c3, sc;  // c1.x: act (split); c3.y32: output
-    unsigned x_bytes, w1_bytes, w2_bytes, w3_bytes, wsc_bytes;
+    unsigned x_bytes, y_bytes, w1_bytes, w2_bytes, w3_bytes, wsc_bytes;
     int tiles_x, tiles_y;
 };
 
@@ -1742,10 +1767,11 @@ __global__ __launch_bounds__(256, 2) void unit_proj_fused_kernel(UnitProjArgs u)
     constexpr int BM = 128, MID = 64;
     constexpr int PW = 18, PPIX = 180, PROWS = 192;
     constexpr int PLANE = PROWS * 128;
-    constexpr int WST_OFF = 2 * PLANE, WSTAGE = 64 * 128;
-    constexpr int T2_OFF = 0, ACT_OFF = 2 * BM * 128, W3_OFF = 4 * BM * 128;
-    constexpr int SMEM_BYTES = W3_OFF + 2 * WSTAGE;
-    static_assert(WST_OFF + 2 * WSTAGE <= W3_OFF && SMEM_BYTES <= 80 * 1024, "LDS plan");
+    constexpr int WBLK = 2 * 64 * 128;                      // one weight block: [K-step][64 rows][128 B]
+    constexpr int WA = 2 * PLANE, WB = WA + WBLK;           // the two blocks of phases 0-1
+    constexpr int T2_OFF = 0, WC = 2 * BM * 128;            // phase 3: third block where the patch tail was
+    constexpr int SMEM_BYTES = WB + WBLK;
+    static_assert(WC + WBLK <= WA && SMEM_BYTES <= 80 * 1024, "LDS plan");
     __shared__ __attribute__((aligned(16))) float smem[SMEM_BYTES / 4];
     char* const sbytes = reinterpret_cast<char*>(smem);
 
@@ -1765,6 +1791,7 @@ __global__ __launch_bounds__(256, 2) void unit_proj_fused_kernel(UnitProjArgs u)
     const int y0 = tyi * 8, x0 = txi * 16;
 
     const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)a1.x, 0, u.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc((void*)c.y32, 0, u.y_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t w1r = __builtin_amdgcn_make_buffer_rsrc((void*)a1.w, 0, u.w1_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t w2r = __builtin_amdgcn_make_buffer_rsrc((void*)a2.w, 0, u.w2_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t w3r = __builtin_amdgcn_make_buffer_rsrc((void*)c.w, 0, u.w3_bytes, 0x00020000);
@@ -1789,7 +1816,7 @@ __global__ __launch_bounds__(256, 2) void unit_proj_fused_kernel(UnitProjArgs u)
                 xr, (__attribute__((address_space(3))) void*)(sbytes + kk * PLANE + (wave * 48 + i * 8) * 128), 16, vo,
                 kk * 128, 0, 0);
     }
-    // 64-row weight blocks by LDS-DMA: 2 pieces per wave
+    // a weight block = 64 rows x 2 K-steps by LDS-DMA: 4 instructions per wave, always
     unsigned wvo1[2], wvo2[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
@@ -1798,15 +1825,16 @@ __global__ __launch_bounds__(256, 2) void unit_proj_fused_kernel(UnitProjArgs u)
         wvo1[i] = (unsigned)(row * MID * 4) + chunk;          // conv1, conv3 and the shortcut: K = 64
         wvo2[i] = (unsigned)(row * (9 * MID) * 4) + chunk;    // conv2: K = 576
     }
-#define FD_WDMA(RSRC, VO, ROWOFF, KT, DST)                                                        \
+#define FD_WBLOCK(RSRC, VO, ROWOFF, KT0, DST)                                                     \
     do {                                                                                          \
-        _Pragma("unroll") for (int i = 0; i < 2; ++i)                                             \
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(                                             \
-                RSRC, (__attribute__((address_space(3))) void*)(sbytes + (DST) + (wave + 4 * i) * 1024), 16,       \
-                VO[i] + (unsigned)(ROWOFF), (KT) * 128, 0, 0);                                    \
+        _Pragma("unroll") for (int kk_ = 0; kk_ < 2; ++kk_)                                       \
+            _Pragma("unroll") for (int i = 0; i < 2; ++i)                                         \
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(                                         \
+                    RSRC, (__attribute__((address_space(3))) void*)(sbytes + (DST) + kk_ * (64 * 128) + (wave + 4 * i) * 1024), \
+                    16, VO[i] + (unsigned)(ROWOFF), ((KT0) + kk_) * 128, 0, 0);                   \
     } while (0)
-    FD_WDMA(w1r, wvo1, 0, 0, WST_OFF);
-    FD_WDMA(w1r, wvo1, 0, 1, WST_OFF + WSTAGE);
+    FD_WBLOCK(w1r, wvo1, 0, 0, WA);
+    FD_WBLOCK(w2r, wvo2, 0, 0, WB);                           // filter tap 0 of the 3x3
     int w_off[2];
 #pragma unroll
     for (int part = 0; part < 2; ++part) w_off[part] = frow * 128 + (((part * 4 + fh) ^ sw) * 16);
@@ -1833,8 +1861,8 @@ __global__ __launch_bounds__(256, 2) void unit_proj_fused_kernel(UnitProjArgs u)
         f16x8 ah[4], al[4], bh[3], bl[3];
 #pragma unroll
         for (int nf = 0; nf < 4; ++nf) {
-            ah[nf] = *reinterpret_cast<const f16x8*>(sbytes + WST_OFF + kk * WSTAGE + w_off[0] + nf * 2048);
-            al[nf] = *reinterpret_cast<const f16x8*>(sbytes + WST_OFF + kk * WSTAGE + w_off[1] + nf * 2048);
+            ah[nf] = *reinterpret_cast<const f16x8*>(sbytes + WA + kk * (64 * 128) + w_off[0] + nf * 2048);
+            al[nf] = *reinterpret_cast<const f16x8*>(sbytes + WA + kk * (64 * 128) + w_off[1] + nf * 2048);
         }
 #pragma unroll
         for (int f = 0; f < 3; ++f) {
@@ -1850,9 +1878,21 @@ __global__ __launch_bounds__(256, 2) void unit_proj_fused_kernel(UnitProjArgs u)
                 acc0[nf][f] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[nf], bh[f], acc0[nf][f], 0, 0, 0);
             }
     }
-    __syncthreads();        // every wave has read the conv1 weights (and its own act rows)
-    FD_WDMA(w2r, wvo2, 0, 0, WST_OFF);
+    // the tile's own act pixels as the shortcut's column operand: rows (2 wave + pf) * 16 + frow,
+    // this lane's 8 channels of each K-step (hi at fh * 16, lo 64 bytes further)
+    f16x8 sact[2][2][2];
+#pragma unroll
+    for (int pf = 0; pf < 2; ++pf) {
+        const int gy = y0 + 2 * wave + pf, gx = x0 + frow;
+        const unsigned vo = (gy < H && gx < W) ? (unsigned)(((img * H + gy) * W + gx) * (MID * 4) + fh * 16) : OOB;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            sact[pf][kk][0] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(xr, vo, kk * 128, 0));
+            sact[pf][kk][1] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(xr, vo + 64u, kk * 128, 0));
+        }
+    }
     {
+        // t1 over act, in place: a lane holds channels nf * 16 + fh * 4 + j of patch row (3 wave + f) * 16 + frow
 #pragma unroll
         for (int nf = 0; nf < 4; ++nf) {
             const f32x4 b = a1.bias ? *reinterpret_cast<const f32x4*>(a1.bias + nf * 16 + fh * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
@@ -1875,10 +1915,11 @@ __global__ __launch_bounds__(256, 2) void unit_proj_fused_kernel(UnitProjArgs u)
             }
         }
     }
-    wait_vmcnt<0>();
-    __syncthreads();
+    __syncthreads();        // t1 complete; every wave has read the conv1 weights
 
-    // ---- phase 1: the 3x3 out of the patch; wave w owns tile rows 2 w and 2 w + 1 ----
+    // ---- phase 1: the 3x3 out of the patch; wave w owns tile rows 2 w and 2 w + 1.  Tap t reads
+    //      block (t + 1) & 1; the next tap's block (after the last tap: the first block of
+    //      phase 3) is requested at the top of the step ----
     f32x4 acc1[4][2];
 #pragma unroll
     for (int nf = 0; nf < 4; ++nf)
@@ -1887,6 +1928,9 @@ __global__ __launch_bounds__(256, 2) void unit_proj_fused_kernel(UnitProjArgs u)
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
         const int dy = tap / 3, dx = tap - dy * 3;
+        const int rd = ((tap + 1) & 1) ? WB : WA, wr_ = ((tap + 1) & 1) ? WA : WB;
+        if (tap + 1 < 9) FD_WBLOCK(w2r, wvo2, 0, 2 * (tap + 1), wr_);
+        else FD_WBLOCK(w3r, wvo1, 0, 0, wr_);
         int p_off[2][2];
 #pragma unroll
         for (int pf = 0; pf < 2; ++pf) {
@@ -1895,51 +1939,41 @@ __global__ __launch_bounds__(256, 2) void unit_proj_fused_kernel(UnitProjArgs u)
 #pragma unroll
             for (int part = 0; part < 2; ++part) p_off[pf][part] = pp * 128 + (((part * 4 + fh) ^ sp) * 16);
         }
+        f16x8 ah[2][4], al[2][4], bh[2][2], bl[2][2];
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
-            const int kt = tap * 2 + kk, cur = kt & 1;
-            if (kt + 1 < 18) FD_WDMA(w2r, wvo2, 0, kt + 1, WST_OFF + (cur ^ 1) * WSTAGE);
-            f16x8 ah[4], al[4], bh[2], bl[2];
 #pragma unroll
             for (int nf = 0; nf < 4; ++nf) {
-                ah[nf] = *reinterpret_cast<const f16x8*>(sbytes + WST_OFF + cur * WSTAGE + w_off[0] + nf * 2048);
-                al[nf] = *reinterpret_cast<const f16x8*>(sbytes + WST_OFF + cur * WSTAGE + w_off[1] + nf * 2048);
+                ah[kk][nf] = *reinterpret_cast<const f16x8*>(sbytes + rd + kk * (64 * 128) + w_off[0] + nf * 2048);
+                al[kk][nf] = *reinterpret_cast<const f16x8*>(sbytes + rd + kk * (64 * 128) + w_off[1] + nf * 2048);
             }
 #pragma unroll
             for (int pf = 0; pf < 2; ++pf) {
-                bh[pf] = *reinterpret_cast<const f16x8*>(sbytes + kk * PLANE + p_off[pf][0]);
-                bl[pf] = *reinterpret_cast<const f16x8*>(sbytes + kk * PLANE + p_off[pf][1]);
+                bh[kk][pf] = *reinterpret_cast<const f16x8*>(sbytes + kk * PLANE + p_off[pf][0]);
+                bl[kk][pf] = *reinterpret_cast<const f16x8*>(sbytes + kk * PLANE + p_off[pf][1]);
             }
-            __builtin_amdgcn_s_setprio(1);
+        }
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
             for (int nf = 0; nf < 4; ++nf)
 #pragma unroll
                 for (int pf = 0; pf < 2; ++pf) {
-                    acc1[nf][pf] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[nf], bh[pf], acc1[nf][pf], 0, 0, 0);
-                    acc1[nf][pf] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[nf], bl[pf], acc1[nf][pf], 0, 0, 0);
-                    acc1[nf][pf] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[nf], bh[pf], acc1[nf][pf], 0, 0, 0);
+                    acc1[nf][pf] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[kk][nf], bh[kk][pf], acc1[nf][pf], 0, 0, 0);
+                    acc1[nf][pf] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[kk][nf], bl[kk][pf], acc1[nf][pf], 0, 0, 0);
+                    acc1[nf][pf] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[kk][nf], bh[kk][pf], acc1[nf][pf], 0, 0, 0);
                 }
-            __builtin_amdgcn_s_setprio(0);
-            wait_vmcnt<0>();
-            pipeline_barrier();
-        }
+        __builtin_amdgcn_s_setprio(0);
+        wait_vmcnt<0>();
+        pipeline_barrier();
     }
 
-    // ---- phase 2: the tile's own act pixels again (operand of the shortcut convolution), the
-    //      first weight block of the last phase, and t2 into its operand image ----
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int row = (wave * 4 + i) * 8 + lrow;
-        const int gy = y0 + (row >> 4), gx = x0 + (row & 15);
-        const bool ok = gy < H && gx < W;
-        const unsigned vo = ok ? (unsigned)(((img * H + gy) * W + gx) * (MID * 4) + (lpos ^ ((row >> 1) & 7)) * 16) : OOB;
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(
-                xr, (__attribute__((address_space(3))) void*)(sbytes + ACT_OFF + kk * (BM * 128) + (wave * 4 + i) * 1024), 16,
-                vo, kk * 128, 0, 0);
-    }
-    FD_WDMA(w3r, wvo1, 0, 0, W3_OFF);
+    // ---- phase 2: t2 = relu(. + b2), split, into the operand image of the last phase (the patch is
+    //      dead: every wave has passed the last barrier) ----
+    // Phase 3 runs 2 steps per 64-channel chunk (main branch, shortcut), step s reading block
+    // ring[s % 3] = {WA, WC, WB}; step 0's block arrived during the last tap.
+    FD_WBLOCK(wsr, wvo1, 0, 0, WC);                           // step 1
     {
 #pragma unroll
         for (int nf = 0; nf < 4; ++nf) {
@@ -1961,88 +1995,111 @@ __global__ __launch_bounds__(256, 2) void unit_proj_fused_kernel(UnitProjArgs u)
             }
         }
     }
-    wait_vmcnt<0>();
-    __syncthreads();
+    pipeline_barrier();
 
-    // ---- phase 3: y = W3 t2 + Wsc act, 64 output channels at a time; per chunk four K-steps
-    //      (main branch kk 0, 1; shortcut kk 0, 1) through the two weight stages ----
-    int t_off[2][2];            // pixel operand of tile rows (2 wave + pf) * 16 + frow
-#pragma unroll
-    for (int pf = 0; pf < 2; ++pf)
-#pragma unroll
-        for (int part = 0; part < 2; ++part) {
-            const int row = (2 * wave + pf) * 16 + frow;
-            t_off[pf][part] = row * 128 + (((part * 4 + fh) ^ sw) * 16);
-        }
-    const int row_g[2] = {(2 * wave) * 16 + frow, (2 * wave + 1) * 16 + frow};
-    long long out_row[2];
+    // ---- phase 3: y = W3 t2 + Wsc act ----
+    int t_off[2][2];            // t2 operand of tile rows (2 wave + pf) * 16 + frow
+    unsigned out_vo[2];         // byte offset of those rows in y (out of range: row outside the image)
 #pragma unroll
     for (int pf = 0; pf < 2; ++pf) {
+        const int row = (2 * wave + pf) * 16 + frow;
+#pragma unroll
+        for (int part = 0; part < 2; ++part) t_off[pf][part] = row * 128 + (((part * 4 + fh) ^ sw) * 16);
         const int gy = y0 + 2 * wave + pf, gx = x0 + frow;
-        out_row[pf] = (gy < H && gx < W) ? ((long long)(img * H + gy) * W + gx) : -1;
+        out_vo[pf] = (gy < H && gx < W) ? (unsigned)(((img * H + gy) * W + gx) * (c.Cout * 4) + fh * 16) : OOB;
     }
-    (void)row_g;
-    const int nch = c.Cout / 64;
-#pragma unroll 1
-    for (int ch = 0; ch < nch; ++ch) {
-        f32x4 accm[4][2], accs[4][2];
+    constexpr int NSTEP = 8;    // 4 chunks x (main, shortcut)
+    f32x4 accm[4][2], accs[4][2];
 #pragma unroll
-        for (int nf = 0; nf < 4; ++nf)
+    for (int s3 = 0; s3 < NSTEP; ++s3) {
+        const int ch = s3 >> 1, st = s3 & 1;
+        const int ring[3] = {WA, WC, WB};
+        const int rd = ring[s3 % 3];
+        if (s3 + 2 < NSTEP) {
+            const int wr_ = ring[(s3 + 2) % 3];
+            if (st == 0) FD_WBLOCK(w3r, wvo1, (ch + 1) * 64 * MID * 4, 0, wr_);
+            else FD_WBLOCK(wsr, wvo1, (ch + 1) * 64 * MID * 4, 0, wr_);
+        }
+        if (st == 0) {
 #pragma unroll
-            for (int pf = 0; pf < 2; ++pf) { accm[nf][pf] = f32x4{0.f, 0.f, 0.f, 0.f}; accs[nf][pf] = accm[nf][pf]; }
+            for (int nf = 0; nf < 4; ++nf)
 #pragma unroll
-        for (int st = 0; st < 4; ++st) {
-            const int kk = st & 1, cur = st & 1;
-            // next weight block: st 0 -> main kk 1, st 1 -> shortcut kk 0, st 2 -> shortcut kk 1,
-            // st 3 -> main kk 0 of the next chunk
-            if (st == 0) FD_WDMA(w3r, wvo1, ch * 64 * MID * 4, 1, W3_OFF + WSTAGE);
-            else if (st == 1) FD_WDMA(wsr, wvo1, ch * 64 * MID * 4, 0, W3_OFF);
-            else if (st == 2) FD_WDMA(wsr, wvo1, ch * 64 * MID * 4, 1, W3_OFF + WSTAGE);
-            else if (ch + 1 < nch) FD_WDMA(w3r, wvo1, (ch + 1) * 64 * MID * 4, 0, W3_OFF);
-            f16x8 ah[4], al[4], bh[2], bl[2];
+                for (int pf = 0; pf < 2; ++pf) { accm[nf][pf] = f32x4{0.f, 0.f, 0.f, 0.f}; accs[nf][pf] = accm[nf][pf]; }
+        }
+        f16x8 ah[2][4], al[2][4], bh[2][2], bl[2][2];
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
 #pragma unroll
             for (int nf = 0; nf < 4; ++nf) {
-                ah[nf] = *reinterpret_cast<const f16x8*>(sbytes + W3_OFF + cur * WSTAGE + w_off[0] + nf * 2048);
-                al[nf] = *reinterpret_cast<const f16x8*>(sbytes + W3_OFF + cur * WSTAGE + w_off[1] + nf * 2048);
+                ah[kk][nf] = *reinterpret_cast<const f16x8*>(sbytes + rd + kk * (64 * 128) + w_off[0] + nf * 2048);
+                al[kk][nf] = *reinterpret_cast<const f16x8*>(sbytes + rd + kk * (64 * 128) + w_off[1] + nf * 2048);
             }
-            const int src = (st < 2 ? T2_OFF : ACT_OFF) + kk * (BM * 128);
 #pragma unroll
             for (int pf = 0; pf < 2; ++pf) {
-                bh[pf] = *reinterpret_cast<const f16x8*>(sbytes + src + t_off[pf][0]);
-                bl[pf] = *reinterpret_cast<const f16x8*>(sbytes + src + t_off[pf][1]);
+                if (st == 0) {
+                    bh[kk][pf] = *reinterpret_cast<const f16x8*>(sbytes + T2_OFF + kk * (BM * 128) + t_off[pf][0]);
+                    bl[kk][pf] = *reinterpret_cast<const f16x8*>(sbytes + T2_OFF + kk * (BM * 128) + t_off[pf][1]);
+                } else {
+                    bh[kk][pf] = sact[pf][kk][0];
+                    bl[kk][pf] = sact[pf][kk][1];
+                }
             }
-            __builtin_amdgcn_s_setprio(1);
+        }
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
             for (int nf = 0; nf < 4; ++nf)
 #pragma unroll
                 for (int pf = 0; pf < 2; ++pf) {
-                    f32x4& d = st < 2 ? accm[nf][pf] : accs[nf][pf];
-                    d = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[nf], bh[pf], d, 0, 0, 0);
-                    d = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[nf], bl[pf], d, 0, 0, 0);
-                    d = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[nf], bh[pf], d, 0, 0, 0);
+                    f32x4& d = st == 0 ? accm[nf][pf] : accs[nf][pf];
+                    d = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[kk][nf], bh[kk][pf], d, 0, 0, 0);
+                    d = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[kk][nf], bl[kk][pf], d, 0, 0, 0);
+                    d = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[kk][nf], bh[kk][pf], d, 0, 0, 0);
                 }
-            __builtin_amdgcn_s_setprio(0);
-            wait_vmcnt<0>();
+        __builtin_amdgcn_s_setprio(0);
+        // The next step's block must have landed.  Younger than it, and allowed to stay in flight:
+        // the block requested at the top of this step (4 instructions) and, in the step after an
+        // epilogue, that epilogue's 8 stores (vector-memory operations retire in issue order).
+        if (s3 + 1 < NSTEP) {
+            constexpr int DMA = 4, STORES = 8;
+            if (s3 + 2 < NSTEP) {
+                if (st == 0 && ch > 0) wait_vmcnt<DMA + STORES>();
+                else wait_vmcnt<DMA>();
+            } else {
+                wait_vmcnt<0>();
+            }
             pipeline_barrier();
         }
-        // a lane holds channels ch * 64 + nf * 16 + fh * 4 + j of tile rows (2 wave + pf) * 16 + frow
+        if (st == 1) {
+            // a lane holds channels ch * 64 + nf * 16 + fh * 4 + j of tile rows (2 wave + pf) * 16 + frow;
+            // always 8 store instructions (rows outside the image are dropped by the range check)
 #pragma unroll
-        for (int nf = 0; nf < 4; ++nf) {
-            const int col = ch * 64 + nf * 16 + fh * 4;
-            f32x4 b = {0.f, 0.f, 0.f, 0.f};
-            if (c.bias) b = *reinterpret_cast<const f32x4*>(c.bias + col);
-            if (u.sc.bias) b += *reinterpret_cast<const f32x4*>(u.sc.bias + col);
+            for (int nf = 0; nf < 4; ++nf) {
+                const int col = ch * 64 + nf * 16 + fh * 4;
+                f32x4 b = {0.f, 0.f, 0.f, 0.f};
+                if (c.bias) b = *reinterpret_cast<const f32x4*>(c.bias + col);
+                if (u.sc.bias) b += *reinterpret_cast<const f32x4*>(u.sc.bias + col);
 #pragma unroll
-            for (int pf = 0; pf < 2; ++pf) {
-                if (out_row[pf] < 0) continue;
-                f32x4 v;
+                for (int pf = 0; pf < 2; ++pf) {
+                    f32x4 v;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) v[j] = accm[nf][pf][j] * c.w_inv_scale + (accs[nf][pf][j] * u.sc.w_inv_scale + b[j]);
-                __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(c.y32 + out_row[pf] * c.Cout + col));
+                    for (int j = 0; j < 4; ++j)
+                        v[j] = accm[nf][pf][j] * c.w_inv_scale + (accs[nf][pf][j] * u.sc.w_inv_scale + b[j]);
+                    typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+                    // The channel offset goes into the instruction's immediate offset, not into an SGPR:
+                    // with a register soffset the compiler inserts no wait state between a 16-byte
+                    // store and the next write of its data registers, and on this chip the store
+                    // then picks up part of the next value (seen as wrong values in lanes 12-15 of
+                    // every 16).
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), yr,
+                                                           out_vo[pf] + (unsigned)((ch * 64 + nf * 16) * 4), 0,
+                                                           2 /* streaming store */);
+                }
             }
         }
     }
-#undef FD_WDMA
+#undef FD_WBLOCK
 #endif
 }
 
@@ -2058,8 +2115,8 @@ int unit_proj_fused_forward(const SplitConvParams& p1, const SplitConvParams& p2
           !psc.relu))
         return FD_OK;
     const long long m_ll = (long long)batch * h * w;
-    const size_t x_bytes = (size_t)m_ll * 64 * 4;
-    if (x_bytes >= (1ull << 31) || !y32) return FD_OK;
+    const size_t x_bytes = (size_t)m_ll * 64 * 4, y_bytes = (size_t)m_ll * 256 * 4;
+    if (y_bytes >= (1ull << 31) || !y32) return FD_OK;
     FD_REQUIRE(act && p1.w && p2.w && p3.w && psc.w, "fused projection unit: NULL tensor");
     UnitProjArgs u;
     SplitKArgs a;
@@ -2077,7 +2134,7 @@ int unit_proj_fused_forward(const SplitConvParams& p1, const SplitConvParams& p2
     u.c3.w_inv_scale = p3.w_inv_scale; u.c3.Cout = 256; u.c3.relu = 0; u.c3.tiles_n = 4;
     u.sc = u.c3;
     u.sc.w = static_cast<const uint8_t*>(psc.w); u.sc.bias = psc.bias; u.sc.w_inv_scale = psc.w_inv_scale; u.sc.y32 = nullptr;
-    u.x_bytes = (unsigned)x_bytes;
+    u.x_bytes = (unsigned)x_bytes; u.y_bytes = (unsigned)y_bytes;
     u.w1_bytes = (unsigned)(s1.packed_floats() * 4); u.w2_bytes = (unsigned)(s2.packed_floats() * 4);
     u.w3_bytes = (unsigned)(s3.packed_floats() * 4); u.wsc_bytes = (unsigned)(ss.packed_floats() * 4);
     u.tiles_x = ceil_div(w, 16); u.tiles_y = ceil_div(h, 8);

@@ -56,7 +56,10 @@ struct fd_detector {
     std::vector<fd::Tap> taps;
     fd::Buf net[fd::NB_COUNT];
     bool keep_taps = false;              // debugging: snapshot every tapped tensor
-    bool fuse_units = true;              // whole-unit kernel for the 64-channel identity units (FD_FUSE_UNITS=0 turns it off)
+    int fuse_units = 3;                  // whole-unit kernels of the 64-channel stage: bit 0 identity units, bit 1 the
+                                         // projection unit, bit 2 also while tensors are kept for inspection (the
+                                         // unit outputs then come from the fused kernels; t1/t2 are not produced);
+                                         // the environment variable FD_FUSE_UNITS overrides
     std::vector<void*> tap_copies;
 };
 
@@ -439,7 +442,7 @@ static int run_unit_split(Plan& pl, const Unit& u, const char* name, const void*
     // the projection unit of the 64-channel stage as one kernel: shortcut and main branch are
     // accumulated together, so neither the shortcut tensor nor t1/t2 exist
     bool whole_proj = false;
-    if (u.has_sc && !pl.dry && !pl.d->keep_taps && pl.d->fuse_units && y32 && !ysplit)
+    if (u.has_sc && !pl.dry && (!pl.d->keep_taps || (pl.d->fuse_units & 4)) && (pl.d->fuse_units & 2) && y32 && !ysplit)
         FD_TRY(unit_proj_fused_forward(u.s_conv1, u.s_conv2, u.s_conv3, u.s_sc, act, n, h, w, y32, pl.stream,
                                        &whole_proj));
     if (u.has_sc) {
@@ -462,7 +465,7 @@ static int run_unit_split(Plan& pl, const Unit& u, const char* name, const void*
         // identity units of the 64-channel stage run as one kernel (nothing between the unit's
         // input and output goes to HBM); the intermediate tensors exist only for inspection
         bool whole = false;
-        if (!u.has_sc && !pl.d->keep_taps && pl.d->fuse_units)
+        if (!u.has_sc && (!pl.d->keep_taps || (pl.d->fuse_units & 4)) && (pl.d->fuse_units & 1))
             FD_TRY(unit_fused_forward(u.s_conv1, u.s_conv2, u.s_conv3, xraw, u.bn1_scale, u.bn1_shift, n, h, w, o3,
                                       pl.stream, &whole));
         if (!whole) {
@@ -700,7 +703,7 @@ int fd_detector_create(fd_ctx* ctx, const fd_param* params, int n_params, const 
         if (params[i].name) t.m[params[i].name] = &params[i];
     fd_detector* d = new fd_detector();
     d->ctx = ctx;
-    if (const char* e = getenv("FD_FUSE_UNITS")) d->fuse_units = atoi(e) != 0;
+    if (const char* e = getenv("FD_FUSE_UNITS")) d->fuse_units = atoi(e);
     d->prop = *cfg;
     const int rc = fd::build(d, t);
     if (rc != FD_OK) {

@@ -1,0 +1,60 @@
+"""The whole-unit kernels of the 64-channel stage (a residual unit's three convolutions, and for the
+first unit also its shortcut convolution, in one launch) against the same unit run as separate
+convolution kernels.  Both paths compute the same float32-grade products; they differ in the order
+in which the three partial products of a split multiply are added, so tensors agree to a few ulps
+rather than bit for bit."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+# frame sizes whose stage-1 map (a quarter of the frame) is not a multiple of the 8 x 16 pixel tile,
+# is smaller than one tile, and spans many tiles
+SIZES = [(1, 37, 41), (3, 64, 96), (2, 333, 517), (1, 270, 480)]
+
+
+def _detector(monkeypatch, mask, keep=False):
+    from facedetection_amd.detection import Detector
+    monkeypatch.setenv("FD_FUSE_UNITS", str(mask))
+    det = Detector("synthetic:0", 0, own_context=True)
+    if keep:
+        det.keep_tensors(True)
+    return det
+
+
+@pytest.mark.parametrize("mask", [1, 2, 3])
+def test_fused_units_give_the_outputs_of_the_separate_kernels(monkeypatch, mask):
+    ref = _detector(monkeypatch, 0)
+    new = _detector(monkeypatch, mask)
+    rng = np.random.default_rng(mask)
+    try:
+        for (b, h, w) in SIZES:
+            frames = rng.integers(0, 256, size=(b, h, w, 3), dtype=np.uint8)
+            rois_a, cls_a, box_a = ref.forward(frames)
+            rois_b, cls_b, box_b = new.forward(frames)
+            np.testing.assert_allclose(rois_b, rois_a, atol=0.01)      # pixels
+            np.testing.assert_allclose(cls_b, cls_a, atol=1e-5)
+            np.testing.assert_allclose(box_b, box_a, atol=1e-5)
+    finally:
+        ref.close()
+        new.close()
+
+
+def test_fused_unit_tensors_match_elementwise(monkeypatch):
+    """Unit outputs as tensors (mask bit 2 keeps the fused kernels on while tensors are recorded)."""
+    ref = _detector(monkeypatch, 0, keep=True)
+    new = _detector(monkeypatch, 7, keep=True)
+    rng = np.random.default_rng(7)
+    try:
+        for (b, h, w) in SIZES:
+            frames = rng.integers(0, 256, size=(b, h, w, 3), dtype=np.uint8)
+            ref.forward(frames)
+            new.forward(frames)
+            for name in ("stage1_unit1", "stage1_unit2", "stage1_unit3"):
+                want, got = ref.tensor(name), new.tensor(name)
+                assert want.shape == got.shape
+                scale = float(np.abs(want).max())
+                assert float(np.abs(got - want).max()) <= 2e-6 * scale, (name, (b, h, w))
+    finally:
+        ref.close()
+        new.close()

@@ -3,7 +3,7 @@
 and without the whole-unit kernel (FD_FUSE_UNITS) on a few frame sizes, including sizes whose
 stage-1 map is not a multiple of the 8 x 16 pixel tile.
 
-    python tools/fuse_check.py
+    python tools/fuse_check.py [mask]      (1: identity units only, 2: projection unit only, 3: both)
 """
 import os
 import sys
@@ -19,7 +19,7 @@ def main():
     torch.cuda.set_device(0)
     os.environ["FD_FUSE_UNITS"] = "0"
     ref = Detector("synthetic:0", 0, own_context=True)
-    os.environ["FD_FUSE_UNITS"] = "1"
+    os.environ["FD_FUSE_UNITS"] = sys.argv[1] if len(sys.argv) > 1 else "3"
     new = Detector("synthetic:0", 0, own_context=True)
     rng = np.random.default_rng(0)
     worst = 0.0
