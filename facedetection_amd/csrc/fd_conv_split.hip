@@ -344,27 +344,32 @@ template <int BM, int BN>
 __device__ __forceinline__ void split_mma_step(const char* stage, const int (&a_off)[2], const int (&b_off)[2],
                                                f32x4 (&acc)[BM / 32][BN / 32]) {
     constexpr int AM = BM / 32, AN = BN / 32;
-    f16x8 ah[AM], al[AM], bh[AN], bl[AN];
+    constexpr int NG = AN > 4 ? 4 : AN;          // column blocks held in registers at a time
+    f16x8 ah[AM], al[AM];
 #pragma unroll
     for (int mi = 0; mi < AM; ++mi) {
         ah[mi] = *reinterpret_cast<const f16x8*>(stage + a_off[0] + mi * 2048);
         al[mi] = *reinterpret_cast<const f16x8*>(stage + a_off[1] + mi * 2048);
     }
 #pragma unroll
-    for (int ni = 0; ni < AN; ++ni) {
-        bh[ni] = *reinterpret_cast<const f16x8*>(stage + b_off[0] + ni * 2048);
-        bl[ni] = *reinterpret_cast<const f16x8*>(stage + b_off[1] + ni * 2048);
-    }
-    __builtin_amdgcn_s_setprio(1);
+    for (int n0 = 0; n0 < AN; n0 += NG) {
+        f16x8 bh[NG], bl[NG];
 #pragma unroll
-    for (int mi = 0; mi < AM; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < AN; ++ni) {
-            acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[mi], bh[ni], acc[mi][ni], 0, 0, 0);
-            acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[mi], bl[ni], acc[mi][ni], 0, 0, 0);
-            acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[mi], bh[ni], acc[mi][ni], 0, 0, 0);
+        for (int ni = 0; ni < NG; ++ni) {
+            bh[ni] = *reinterpret_cast<const f16x8*>(stage + b_off[0] + (n0 + ni) * 2048);
+            bl[ni] = *reinterpret_cast<const f16x8*>(stage + b_off[1] + (n0 + ni) * 2048);
         }
-    __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int mi = 0; mi < AM; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < NG; ++ni) {
+                acc[mi][n0 + ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[mi], bh[ni], acc[mi][n0 + ni], 0, 0, 0);
+                acc[mi][n0 + ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[mi], bl[ni], acc[mi][n0 + ni], 0, 0, 0);
+                acc[mi][n0 + ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[mi], bh[ni], acc[mi][n0 + ni], 0, 0, 0);
+            }
+        __builtin_amdgcn_s_setprio(0);
+    }
 }
 
 // Which row of the [M][Cout] output a tile-local row is (-1: none).  Linear tiles are BM
@@ -545,14 +550,22 @@ __device__ __forceinline__ void pipeline_barrier() {
 // NS pipeline stages: a K-step's loads are issued NS-1 steps before their use.  Two stages for
 // the 128-row tiles (two workgroups per CU share 160 KB of LDS; three stages measured slower on
 // the 128x64 tile), four for the 64x64 tile, whose small grids leave one wave per SIMD.
-template <int BM, int BN, int NS>
-__global__ __launch_bounds__(256, 2) void conv_split_glds_kernel(SplitKArgs a, unsigned x_bytes, unsigned w_bytes) {
+// WAVES = 4: a 2 x 2 grid of waves, two workgroups per CU.  WAVES = 8: a 4 x 2 grid of waves over
+// a tile twice as tall, one workgroup per CU; per multiply the larger tile moves 25 % fewer bytes
+// from L2 into LDS, which is what bounds the long-K layers (the 128 x 128 loop of the RPN 3x3
+// takes 976 us with the MFMAs removed and 1141 us with the LDS-DMA removed, 1476 us as it is).
+template <int BM, int BN, int NS, int WAVES = 4>
+__global__ __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) void conv_split_glds_kernel(SplitKArgs a, unsigned x_bytes,
+                                                                                      unsigned w_bytes) {
 #if defined(__HIP_DEVICE_COMPILE__)   // buffer-resource builtins exist in device code only; the host pass needs just the stub
-    using T = SplitTile<BM, BN>;
-    constexpr int GA = BM / 32, GB = BN / 32;   // 8-row groups per wave per K-step
+    constexpr int WROWS = BM / (WAVES / 2);     // rows of the tile per wave row
+    using T = SplitTile<2 * WROWS, BN>;         // per-wave geometry: that of a 2 x 2 grid over 2 WROWS rows
+    constexpr int GA = BM / (8 * WAVES), GB = BN / (8 * WAVES);   // 8-row groups per wave per K-step
     constexpr int PIECES = GA + GB;             // LDS-DMA instructions per wave and stage
-    constexpr int STAGE = T::STAGE;
-    constexpr int SMEM = (NS * STAGE > T::EPI) ? NS * STAGE : T::EPI;
+    constexpr int STAGE = (BM + BN) * 32;       // dwords per pipeline stage
+    constexpr int EPI = WAVES * 32 * T::LDC;    // epilogue staging: one 32-row slice per wave
+    constexpr int SMEM = (NS * STAGE > EPI) ? NS * STAGE : EPI;
+    static_assert(BM % (8 * WAVES) == 0 && BN % (8 * WAVES) == 0 && WROWS % 32 == 0 && SMEM * 4 <= 160 * 1024, "tile shape");
     static_assert(NS >= 2 && NS <= 4 && (NS - 2) * PIECES < 64, "pipeline depth");
     __shared__ __attribute__((aligned(16))) float smem[SMEM];
 
@@ -580,7 +593,7 @@ __global__ __launch_bounds__(256, 2) void conv_split_glds_kernel(SplitKArgs a, u
     bool mval[GA];
 #pragma unroll
     for (int i = 0; i < GA; ++i) {
-        const int row = (wave + 4 * i) * 8 + lrow;                  // row inside the tile
+        const int row = (wave + WAVES * i) * 8 + lrow;              // row inside the tile
         const int chunk = lpos ^ ((row >> 1) & 7);
         const int m = tile_m * BM + row;
         mval[i] = m < a.M;
@@ -597,7 +610,7 @@ __global__ __launch_bounds__(256, 2) void conv_split_glds_kernel(SplitKArgs a, u
     unsigned bvo[GB];                            // weights: per-lane offset, constant over the K loop
 #pragma unroll
     for (int i = 0; i < GB; ++i) {
-        const int row = (wave + 4 * i) * 8 + lrow;
+        const int row = (wave + WAVES * i) * 8 + lrow;
         const int chunk = lpos ^ ((row >> 1) & 7);
         bvo[i] = (unsigned)((tile_n * BN + row) * a.K * 4 + chunk * 16);
     }
@@ -631,10 +644,10 @@ __global__ __launch_bounds__(256, 2) void conv_split_glds_kernel(SplitKArgs a, u
         float* sa_ = smem + (STG) * STAGE;                                                        \
         _Pragma("unroll") for (int i = 0; i < GA; ++i)                                            \
             __builtin_amdgcn_raw_ptr_buffer_load_lds(                                             \
-                xr, (__attribute__((address_space(3))) void*)(sa_ + (wave + 4 * i) * 256), 16, avo[i], coff * 4, 0, 0); \
+                xr, (__attribute__((address_space(3))) void*)(sa_ + (wave + WAVES * i) * 256), 16, avo[i], coff * 4, 0, 0); \
         _Pragma("unroll") for (int i = 0; i < GB; ++i)                                            \
             __builtin_amdgcn_raw_ptr_buffer_load_lds(                                             \
-                wr, (__attribute__((address_space(3))) void*)(sa_ + BM * 32 + (wave + 4 * i) * 256), 16, \
+                wr, (__attribute__((address_space(3))) void*)(sa_ + BM * 32 + (wave + WAVES * i) * 256), 16, \
                 bvo[i], (kb + (KT)) * 128, 0, 0);                                                        \
         coff += SBK;                                                                              \
         if (coff >= a.Cin) {                                                                      \
@@ -669,14 +682,14 @@ __global__ __launch_bounds__(256, 2) void conv_split_glds_kernel(SplitKArgs a, u
 #pragma unroll
     for (int part = 0; part < 2; ++part) {
         const int pos = ((part * 4 + fh) ^ sw) * 16;
-        a_off[part] = (wm * (BM / 2) + frow) * 128 + pos;
+        a_off[part] = (wm * WROWS + frow) * 128 + pos;
         b_off[part] = (BM + wn * (BN / 2) + frow) * 128 + pos;
     }
 
 #define FD_STEP(CUR, KT)                                                                          \
     do {                                                                                          \
         if ((KT) + NS - 1 < nk) FD_ISSUE((KT) + NS - 1, ((CUR) + NS - 1) % NS);                   \
-        split_mma_step<BM, BN>(sbase + (CUR) * STAGE * 4, a_off, b_off, acc);                     \
+        split_mma_step<2 * WROWS, BN>(sbase + (CUR) * STAGE * 4, a_off, b_off, acc);              \
         FD_WAIT(min(NS - 2, nk - 2 - (KT)));                                                      \
         pipeline_barrier();                                                                       \
     } while (0)
@@ -705,14 +718,14 @@ __global__ __launch_bounds__(256, 2) void conv_split_glds_kernel(SplitKArgs a, u
         SplitKArgs e = a;            // raw scaled partial sums; bias, ReLU, residual and split follow in the finish kernel
         e.y32 = a.partial + (size_t)ks * a.M * a.Cout;
         e.ysplit = nullptr; e.bias = nullptr; e.res = nullptr; e.relu = 0;
-        split_epilogue16<BM, BN>(e, smem, tile_m, tile_n, wave, lane, acc);
+        split_epilogue16_rows<2 * WROWS, BN, false>(e, smem, LinearRows{tile_m * BM, a.M}, tile_n, wave, lane, acc);
     } else {
-        split_epilogue16<BM, BN>(a, smem, tile_m, tile_n, wave, lane, acc);
+        split_epilogue16_rows<2 * WROWS, BN, false>(a, smem, LinearRows{tile_m * BM, a.M}, tile_n, wave, lane, acc);
     }
 #endif
 }
 
-template <int BM, int BN, int NS>
+template <int BM, int BN, int NS, int WAVES = 4>
 static int launch_split_glds(const SplitKArgs& a, size_t x_bytes, size_t w_bytes, hipStream_t stream) {
     static const std::string name = std::string("conv_split_") + std::to_string(BM) + "x" + std::to_string(BN);
     ProfScope scope(stream, name.c_str(), 2.0 * a.M * a.Cout * (double)a.K,
@@ -721,8 +734,8 @@ static int launch_split_glds(const SplitKArgs& a, size_t x_bytes, size_t w_bytes
     SplitKArgs k = a;
     const int tiles_m = ceil_div(a.M, BM);
     k.tiles_n = ceil_div(a.Cout, BN);
-    hipLaunchKernelGGL((conv_split_glds_kernel<BM, BN, NS>), dim3(tiles_m * k.tiles_n * k.ksplit), dim3(256), 0, stream,
-                       k, (unsigned)x_bytes, (unsigned)w_bytes);
+    hipLaunchKernelGGL((conv_split_glds_kernel<BM, BN, NS, WAVES>), dim3(tiles_m * k.tiles_n * k.ksplit),
+                       dim3(WAVES * 64), 0, stream, k, (unsigned)x_bytes, (unsigned)w_bytes);
     FD_LAUNCH_CHECK();
     return FD_OK;
 }
@@ -1075,6 +1088,13 @@ static int split_conv_dispatch(const SplitConvParams& p, const void* x_split, co
         return launch_split<64, 64, false, true>(a, stream);
     }
     if (small) {
+        // Large grids run eight-wave workgroups on 256-row tiles (one per CU): per multiply they move
+        // half (256 x 256) or three quarters (256 x 128) of the bytes from L2 into LDS and out of
+        // LDS into registers that the 128 x 128 tile does (RPN 3x3: 1476 -> 1319 us; 752 -> 805
+        // frames/s over all layers, same box, two streams).
+        const long long t256 = (long long)ceil_div(a.M, 256) * ceil_div(s.cout, 128);
+        if (s.cout >= 256 && a.K >= 128 && t256 >= 448) return launch_split_glds<256, 256, 2, 8>(a, x_bytes, w_bytes, stream);
+        if (s.cout > 64 && a.K >= 128 && t256 >= 448) return launch_split_glds<256, 128, 3, 8>(a, x_bytes, w_bytes, stream);
         if (s.cout > 64 && t128 >= 384) return launch_split_glds<128, 128, 2>(a, x_bytes, w_bytes, stream);
         if (t12864 >= 384) return launch_split_glds<128, 64, 2>(a, x_bytes, w_bytes, stream);
         return launch_split_glds<64, 64, 4>(a, x_bytes, w_bytes, stream);
