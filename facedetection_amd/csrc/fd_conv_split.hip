@@ -468,7 +468,11 @@ __device__ __forceinline__ void split_epilogue16_rows(const SplitKArgs& a, float
                 }
             }
         }
-        __syncthreads();
+        // The staging slice is private to the wave (LDS operations of a wave execute in order), so
+        // only the first use needs a workgroup barrier: the slice overlays the pipeline stages other
+        // waves may still be reading.
+        if (mi == 0) __syncthreads();
+        else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
         for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
@@ -479,7 +483,7 @@ __device__ __forceinline__ void split_epilogue16_rows(const SplitKArgs& a, float
                     if (a.relu) v = fmaxf(v, 0.f);
                     Cs[(mb * 16 + (lane >> 4) * 4 + r) * LDC + ni * 16 + (lane & 15)] = v;
                 }
-        __syncthreads();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
         for (int ps = 0; ps < PASSES; ++ps) {
             const int lrow2 = ps * RPP + erow;
