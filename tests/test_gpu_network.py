@@ -52,6 +52,9 @@ CONV_CASES = [
     (3, 7, 7, 512, 512, 3, 2, 1, "bias+relu"),
     (1, 150, 200, 64, 256, 1, 1, 0, "res"),          # large M: 128x128 tiles
     (1, 140, 180, 64, 64, 3, 1, 1, "bias+relu"),     # large M, 64 outputs: 128x64 tiles
+    (2, 250, 301, 64, 128, 3, 1, 1, "bias+relu"),    # grid fills the chip: 8-wave 256x128 tiles, ragged last row tile
+    (1, 200, 301, 128, 264, 1, 1, 0, "res"),         # 8-wave 256x256 tiles, 8 channels in the last column tile
+    (1, 180, 330, 32, 512, 3, 1, 1, "res"),          # 8-wave 256x256 tiles, K = 288
 ]
 
 
