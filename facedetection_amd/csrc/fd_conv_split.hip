@@ -2417,10 +2417,9 @@ __global__ __launch_bounds__(256, OCC) void stem_pool_kernel(StemPoolArgs a, uns
     constexpr int CH = 2 * PH + 1, CW = 2 * PW + 1;   // convolution patch
     static_assert(CH * CW <= BM, "patch must fit the M tile");
     using T = SplitTile<BM, BN>;
-    constexpr int RA = BM / 32, GB = BN / 32;
     constexpr int STAGE = T::STAGE;
     constexpr int LDP = COUT + 4;                     // patch row pitch in floats
-    constexpr int SMEM = (2 * STAGE > BM * LDP) ? 2 * STAGE : BM * LDP;
+    constexpr int SMEM = (2 * STAGE > BM * LDP) ? 2 * STAGE : BM * LDP;       // dwords; also holds image + weights
     __shared__ __attribute__((aligned(16))) float smem[SMEM];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -2433,48 +2432,50 @@ __global__ __launch_bounds__(256, OCC) void stem_pool_kernel(StemPoolArgs a, uns
     const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, w_bytes, 0x00020000);
     constexpr unsigned OOB = 0x80000000u;
 
-    // activations by LDS-DMA.  In the planar image the 8 pixels of a kernel row are 64 contiguous
-    // bytes in the hi plane and 64 in the lo plane, which is exactly a staged row [32 hi | 32 lo]:
-    // the lane at chunk position p of row r fetches chunk c = p ^ ((r >> 1) & 7), i.e. pixels
-    // 2 (c & 3), 2 (c & 3) + 1 of plane c >> 2.  The zero columns of the image stand in for the
-    // horizontal padding; rows above / below the image go out of range and read zeros.
-    const int lrow = lane >> 3, lpos = lane & 7;
-    int hi0[RA];
-    int abase[RA];
-    bool mval[RA];
+    // The patch's receptive field -- IH x IWC columns of the planar staged image, both planes --
+    // and all 7 K-steps of the weights are brought into LDS once (LDS-DMA).  The MFMA operands
+    // are read straight out of that image: for patch pixel (pr, pc) and kernel row kh the 8 window
+    // pixels are 64 contiguous bytes of image row 2 pr + kh starting at column 2 pc (pixel x lives
+    // in column x + 3, so the window of output ox starts at column 2 ox: 16-byte aligned), i.e.
+    // exactly the four 16-byte hi chunks of a K-step row, and the same bytes of the lo plane are
+    // its lo chunks.  Nothing is expanded, so L2 -> LDS traffic is the image once (22 KB per tile)
+    // instead of one 128-byte row per patch pixel and kernel row (226 KB).  The zero columns of
+    // the image stand in for the horizontal padding; rows above / below the image go out of range
+    // and read zeros.
+    constexpr int IH = 2 * (CH - 1) + 7, IWC = 2 * (CW - 1) + 8;   // image rows, 8-byte columns
+    constexpr int IROW = IWC * 8;                                  // bytes per image row in LDS
+    static_assert(IROW % 16 == 0, "image rows are whole 16-byte chunks");
+    constexpr int ICH = IROW / 16;                                 // chunks per row
+    constexpr int IPLANE = IH * IROW;
+    constexpr int IMG_BYTES = ((2 * IPLANE + 1023) / 1024) * 1024;
+    constexpr int WGT_BYTES = 7 * 64 * 128;
+    static_assert(IMG_BYTES + WGT_BYTES <= SMEM * 4, "LDS plan");
+    char* const sbytes = reinterpret_cast<char*>(smem);
+    {
+        const int iy0 = 2 * oy0 - 3, ix0 = 2 * ox0;                // first image row, first column
+        constexpr int NCHUNK = 2 * IH * ICH;
+        for (int base = wave * 64; base < NCHUNK; base += 256) {
+            const int idx = base + lane;
+            const int pl = idx / (IH * ICH), rem = idx - pl * (IH * ICH);
+            const int r = rem / ICH, c = rem - r * ICH;
+            const int iy = iy0 + r;
+            const bool ok = idx < NCHUNK && (unsigned)iy < (unsigned)a.H;
+            const unsigned vo = ok ? (unsigned)(pl * a.plane_bytes) + (unsigned)(((img * a.H + iy) * a.Wpad + ix0) * 8 + c * 16) : OOB;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (__attribute__((address_space(3))) void*)(sbytes + base * 16), 16, vo, 0,
+                                                     0, 0);
+        }
+        const int lrow = lane >> 3, lpos = lane & 7;
 #pragma unroll
-    for (int i = 0; i < RA; ++i) {
-        const int row = (wave + 4 * i) * 8 + lrow;
-        const int c = lpos ^ ((row >> 1) & 7);
-        const int pr = row / CW, pc = row - pr * CW;
-        const int oy = oy0 + pr, ox = ox0 + pc;
-        mval[i] = row < CH * CW && (unsigned)oy < (unsigned)a.Ho && (unsigned)ox < (unsigned)a.Wo;
-        hi0[i] = oy * 2 - 3;
-        // pixel x lives in column x + 3, so the window's first column is 2 ox: 16-byte aligned
-        abase[i] = (int)((c >> 2) * a.plane_bytes) + ((img * a.H + hi0[i]) * a.Wpad + ox * 2 + 2 * (c & 3)) * 8;
-    }
-    unsigned bvo[GB];
+        for (int kt = 0; kt < 7; ++kt)
 #pragma unroll
-    for (int i = 0; i < GB; ++i) {
-        const int row = (wave + 4 * i) * 8 + lrow;
-        bvo[i] = (unsigned)(row * 224 * 4 + (lpos ^ ((row >> 1) & 7)) * 16);
+            for (int i = 0; i < 2; ++i) {
+                const int row = (wave + 4 * i) * 8 + lrow;
+                const unsigned vo = (unsigned)(row * 224 * 4 + (lpos ^ ((row >> 1) & 7)) * 16);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(
+                    wr, (__attribute__((address_space(3))) void*)(sbytes + IMG_BYTES + kt * (64 * 128) + (wave + 4 * i) * 1024), 16,
+                    vo, kt * 128, 0, 0);
+            }
     }
-    constexpr int NK = 7;                             // one K-step per kernel row
-
-#define FD_ISSUE(KT, STG)                                                                         \
-    do {                                                                                          \
-        float* sa_ = smem + (STG) * STAGE;                                                        \
-        _Pragma("unroll") for (int i = 0; i < RA; ++i) {                                          \
-            const bool ok_ = mval[i] && (unsigned)(hi0[i] + (KT)) < (unsigned)a.H;                \
-            const unsigned vo_ = ok_ ? (unsigned)(abase[i] + (KT) * a.Wpad * 8) : OOB;            \
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(                                             \
-                xr, (__attribute__((address_space(3))) void*)(sa_ + (wave + 4 * i) * 256), 16, vo_, 0, 0, 0); \
-        }                                                                                         \
-        _Pragma("unroll") for (int i = 0; i < GB; ++i)                                            \
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(                                             \
-                wr, (__attribute__((address_space(3))) void*)(sa_ + BM * 32 + (wave + 4 * i) * 256), 16, \
-                bvo[i], (KT) * 128, 0, 0);                                                        \
-    } while (0)
 
     f32x4 acc[T::AM][T::AN];
 #pragma unroll
@@ -2483,47 +2484,64 @@ __global__ __launch_bounds__(256, OCC) void stem_pool_kernel(StemPoolArgs a, uns
         for (int ni = 0; ni < T::AN; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int frow = lane & 15, fh = lane >> 4;
     const int sw = (frow >> 1) & 7;
-    const char* sbase = reinterpret_cast<const char*>(smem);
-    int a_off[2], b_off[2];
+    int x_off[T::AM];            // hi chunk of kernel row 0 for patch row wm * (BM / 2) + mi * 16 + frow
 #pragma unroll
-    for (int part = 0; part < 2; ++part) {
-        const int pos = ((part * 4 + fh) ^ sw) * 16;
-        a_off[part] = (wm * (BM / 2) + frow) * 128 + pos;
-        b_off[part] = (BM + wn * (BN / 2) + frow) * 128 + pos;
+    for (int mi = 0; mi < T::AM; ++mi) {
+        int row = wm * (BM / 2) + mi * 16 + frow;
+        if (row >= CH * CW) row = CH * CW - 1;           // rows beyond the patch: any valid address (masked later)
+        const int pr = row / CW, pc = row - pr * CW;
+        x_off[mi] = (2 * pr) * IROW + (2 * pc + 2 * fh) * 8;
     }
-
-    FD_ISSUE(0, 0);
+    int w_off[2];
+#pragma unroll
+    for (int part = 0; part < 2; ++part)
+        w_off[part] = IMG_BYTES + (wn * (BN / 2) + frow) * 128 + (((part * 4 + fh) ^ sw) * 16);
     wait_vmcnt<0>();
     __syncthreads();
 #pragma unroll
-    for (int kt = 0; kt < NK; ++kt) {
-        const int cur = kt & 1;
-        if (kt + 1 < NK) FD_ISSUE(kt + 1, cur ^ 1);
-        split_mma_step<BM, BN>(sbase + cur * STAGE * 4, a_off, b_off, acc);
-        wait_vmcnt<0>();
-        __syncthreads();
-    }
-#undef FD_ISSUE
-
-    // the convolution patch, bias + ReLU applied, as float32 rows of LDP floats
-    float* patch = smem;
-    float bias_v[T::AN];
+    for (int kt = 0; kt < 7; ++kt) {
+        // weights as the MFMA's row operand: a lane ends up with 4 consecutive channels of a
+        // patch pixel, which go into the patch as one 16-byte LDS write
+        f16x8 wh[T::AN], wl[T::AN];
 #pragma unroll
-    for (int ni = 0; ni < T::AN; ++ni) bias_v[ni] = a.bias ? a.bias[wn * 32 + ni * 16 + (lane & 15)] : 0.f;
+        for (int ni = 0; ni < T::AN; ++ni) {
+            wh[ni] = *reinterpret_cast<const f16x8*>(sbytes + w_off[0] + kt * (64 * 128) + ni * 2048);
+            wl[ni] = *reinterpret_cast<const f16x8*>(sbytes + w_off[1] + kt * (64 * 128) + ni * 2048);
+        }
 #pragma unroll
-    for (int mi = 0; mi < T::AM; ++mi)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int row = wm * (BM / 2) + mi * 16 + (lane >> 4) * 4 + r;
-            const int pr = row / CW, pc = row - pr * CW;
-            const bool ok = row < CH * CW && (unsigned)(oy0 + pr) < (unsigned)a.Ho &&
-                            (unsigned)(ox0 + pc) < (unsigned)a.Wo;
+        for (int mi = 0; mi < T::AM; ++mi) {
+            const f16x8 xh = *reinterpret_cast<const f16x8*>(sbytes + x_off[mi] + kt * IROW);
+            const f16x8 xl = *reinterpret_cast<const f16x8*>(sbytes + IPLANE + x_off[mi] + kt * IROW);
 #pragma unroll
             for (int ni = 0; ni < T::AN; ++ni) {
-                const float v = fmaxf(acc[mi][ni][r] * a.w_inv_scale + bias_v[ni], 0.f);
-                patch[row * LDP + wn * 32 + ni * 16 + (lane & 15)] = ok ? v : 0.f;
+                acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[ni], xh, acc[mi][ni], 0, 0, 0);
+                acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[ni], xl, acc[mi][ni], 0, 0, 0);
+                acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[ni], xh, acc[mi][ni], 0, 0, 0);
             }
         }
+    }
+    __syncthreads();             // every wave is done with the image and the weights: the patch overlays them
+
+    // the convolution patch, bias + ReLU applied, as float32 rows of LDP floats: acc[mi][ni] holds
+    // channels wn * 32 + ni * 16 + fh * 4 .. + 3 of patch row wm * (BM / 2) + mi * 16 + frow
+    float* patch = smem;
+    f32x4 bias_v[T::AN];
+#pragma unroll
+    for (int ni = 0; ni < T::AN; ++ni)
+        bias_v[ni] = a.bias ? *reinterpret_cast<const f32x4*>(a.bias + wn * 32 + ni * 16 + fh * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int mi = 0; mi < T::AM; ++mi) {
+        const int row = wm * (BM / 2) + mi * 16 + frow;
+        const int pr = row / CW, pc = row - pr * CW;
+        const bool ok = row < CH * CW && (unsigned)(oy0 + pr) < (unsigned)a.Ho && (unsigned)(ox0 + pc) < (unsigned)a.Wo;
+#pragma unroll
+        for (int ni = 0; ni < T::AN; ++ni) {
+            f32x4 v;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = ok ? fmaxf(acc[mi][ni][j] * a.w_inv_scale + bias_v[ni][j], 0.f) : 0.f;
+            *reinterpret_cast<f32x4*>(&patch[row * LDP + wn * 32 + ni * 16 + fh * 4]) = v;
+        }
+    }
     __syncthreads();
 
     // pooling: one item = 8 channels of one pooled pixel
