@@ -113,8 +113,19 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29512")
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local))
+        # RCCL prints a version banner on the C-level stdout when the communicator comes up; stdout
+        # carries the one JSON line, so the banner is sent to stderr (first collective included)
+        sys.stdout.flush()
+        saved_stdout = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            dist.init_process_group(backend="nccl", rank=rank, world_size=world,
+                                    device_id=torch.device("cuda", local))
+            dist.barrier()
+            torch.cuda.synchronize()
+        finally:
+            os.dup2(saved_stdout, 1)
+            os.close(saved_stdout)
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
 

@@ -3,7 +3,11 @@
 with its own scratch context per stream), to see how much the HBM-bound and the MFMA-bound
 kernels of different micro-batches overlap.
 
-    python tools/stream_probe.py [frames=128] [micro_batch=8] [streams=1,2,3]
+    python tools/stream_probe.py [frames=128] [micro_batch=8] [streams=1,2,3] [cu_split]
+
+With a fourth argument the S streams are created with complementary CU masks (stream k gets every
+S-th CU of each XCD), so kernels of different micro-batches run side by side on disjoint CUs
+instead of one after the other.
 """
 import os
 import sys
@@ -16,6 +20,31 @@ from bench import make_frames  # noqa: E402
 from facedetection_amd.detection import Detector  # noqa: E402
 
 
+def masked_stream(k, S, n_cu=256):
+    """A HIP stream limited to the CUs with index k modulo S, wrapped for torch."""
+    import ctypes
+    # the HIP runtime this process already uses (torch ships its own copy)
+    path = "libamdhip64.so"
+    with open("/proc/self/maps") as f:
+        for line in f:
+            if "libamdhip64" in line:
+                path = line.split()[-1]
+                break
+    hip = ctypes.CDLL(path)
+    words = n_cu // 32
+    mask = (ctypes.c_uint32 * words)()
+    # The runtime only accepts masks that are whole bytes: with 8 XCDs a byte is one CU index on
+    # every XCD, so byte j -> stream j modulo S gives each stream the same share of every XCD.
+    for j in range(n_cu // 8):
+        if j % S == k:
+            mask[j // 4] |= 0xFF << (8 * (j % 4))
+    h = ctypes.c_void_p()
+    rc = hip.hipExtStreamCreateWithCUMask(ctypes.byref(h), ctypes.c_uint32(words), mask)
+    if rc != 0:
+        raise RuntimeError("hipExtStreamCreateWithCUMask failed: %d" % rc)
+    return torch.cuda.ExternalStream(h.value)
+
+
 def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 128
     B = int(sys.argv[2]) if len(sys.argv) > 2 else 8
@@ -25,7 +54,10 @@ def main():
     frames = make_frames(n, dev, seed=0)
     for S in ss:
         dets = [Detector("synthetic:0", 0, own_context=True) for _ in range(S)]
-        streams = [torch.cuda.Stream() for _ in range(S)]
+        if len(sys.argv) > 4 and S > 1:
+            streams = [masked_stream(k, S) for k in range(S)]
+        else:
+            streams = [torch.cuda.Stream() for _ in range(S)]
 
         def step():
             outs = []
