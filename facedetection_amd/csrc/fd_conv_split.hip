@@ -1077,6 +1077,10 @@ static int split_conv_dispatch(const SplitConvParams& p, const void* x_split, co
         if (a.ksplit > 1) {
             a.partial = out.splitk_ws;
             if (pre_scale) FD_TRY((launch_split_reg<64, 64, REG_PRE>(a, x_bytes, w_bytes, stream)));
+            // larger tiles re-read the weights (the dominant traffic here) half as often; the tile shape
+            // does not change the order in which an output element accumulates its K range, so a
+            // frame's result still does not depend on how many frames share the launch
+            else if (a.M >= 1024 && s.cout >= 512) FD_TRY((launch_split_glds<128, 128, 2>(a, x_bytes, w_bytes, stream)));
             else FD_TRY((launch_split_glds<64, 64, 4>(a, x_bytes, w_bytes, stream)));
             return split_k_finish(a, stream);
         }
