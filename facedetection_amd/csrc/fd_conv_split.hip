@@ -1104,7 +1104,7 @@ static int split_conv_dispatch(const SplitConvParams& p, const void* x_split, co
         if (s.cout >= 256 && a.K >= 128 && t256 >= 448) return launch_split_glds<256, 256, 2, 8>(a, x_bytes, w_bytes, stream);
         if (s.cout > 64 && a.K >= 128 && t256 >= 448) return launch_split_glds<256, 128, 3, 8>(a, x_bytes, w_bytes, stream);
         if (s.cout > 64 && t128 >= 384) return launch_split_glds<128, 128, 2>(a, x_bytes, w_bytes, stream);
-        if (t12864 >= 384) return launch_split_glds<128, 64, 2>(a, x_bytes, w_bytes, stream);
+        if (t12864 >= 384) return launch_split_glds<128, 64, 3>(a, x_bytes, w_bytes, stream);
         return launch_split_glds<64, 64, 4>(a, x_bytes, w_bytes, stream);
     }
     if (s.cout > 64 && t128 >= 384) return launch_split<128, 128, false>(a, stream);
