@@ -21,6 +21,7 @@ SOURCES = [
     ("fd_image.hip", ["-ffp-contract=off"]),
     ("fd_conv.hip", []),
     ("fd_conv_split.hip", []),
+    ("fd_conv_fused.hip", []),
     ("fd_detector.hip", []),
 ]
 COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]

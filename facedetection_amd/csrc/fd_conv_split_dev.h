@@ -1,0 +1,258 @@
+// Device-side pieces shared by the split-precision convolution kernels (fd_conv_split.hip: the
+// general kernels; fd_conv_fused.hip: the fused stem, bottleneck tail and whole-unit kernels):
+// the kernel argument block, tile geometry, the MFMA step of a wave, the epilogues and the
+// synchronisation helpers.
+#pragma once
+#include "fd_conv_split.h"
+#include "fd_split.h"
+
+namespace fd {
+
+struct SplitKArgs {
+    const uint8_t* x;        // split activations (or the split staged image for the stem)
+    const uint8_t* w;        // split packed weights
+    const float* bias;
+    const float* res;        // float32 residual [M][Cout] or NULL
+    float* y32;              // float32 output or NULL
+    uint8_t* ysplit;         // split output or NULL
+    const float* post_scale; // BatchNorm+ReLU applied to the split output only (NULL: raw)
+    const float* post_shift;
+    const float* pre_scale;  // PRE kernels: x is float32 and enters as split(relu(x * pre_scale[c] + pre_shift[c]))
+    const float* pre_shift;
+    float w_inv_scale;
+    int H, W, Cin, Ho, Wo, Cout, KW, stride, pad, K, M, relu, tiles_n;
+    // split-K (small grids): workgroup ks of a tile sums K-steps [ks * kchunk, (ks + 1) * kchunk) and
+    // writes its scaled partial sums to partial[ks][M][Cout]; split_k_finish_kernel adds them up
+    int ksplit, kchunk;
+    float* partial;
+};
+
+constexpr int SBK = 32;      // k per K-step
+constexpr int SLDK = 36;     // staged row: 128 B of data + 16 B pad, in dwords
+
+template <int BM, int BN>
+struct SplitTile {
+    static constexpr int STAGE = (BM + BN) * 32;      // dwords per pipeline stage
+    static constexpr int WN = BN / 2;
+    static constexpr int LDC = WN + 4;
+    static constexpr int EPI = 4 * 32 * LDC;          // epilogue staging, dwords
+    static constexpr int SMEM = (2 * STAGE > EPI) ? 2 * STAGE : EPI;
+    static constexpr int AM = BM / 32, AN = BN / 32;  // 16x16 blocks per wave
+};
+
+// Geometry of the epilogue's row passes: after the transpose through LDS a lane owns 8
+// consecutive channels of one row per pass.
+template <int BM, int BN>
+struct SplitEpi {
+    static constexpr int WN = BN / 2;
+    static constexpr int L8 = WN / 8;           // lanes per row
+    static constexpr int RPP = 64 / L8;         // rows per pass
+    static constexpr int PASSES = 32 / RPP;     // passes per 32-row group
+    static constexpr int GROUPS = BM / 64;      // 32-row groups per wave
+};
+
+// all MFMAs of one K-step (32 k) of a wave's tile from the stage at `stage`
+template <int BM, int BN>
+__device__ __forceinline__ void split_mma_step(const char* stage, const int (&a_off)[2], const int (&b_off)[2],
+                                               f32x4 (&acc)[BM / 32][BN / 32]) {
+    constexpr int AM = BM / 32, AN = BN / 32;
+    constexpr int NG = AN > 4 ? 4 : AN;          // column blocks held in registers at a time
+    f16x8 ah[AM], al[AM];
+#pragma unroll
+    for (int mi = 0; mi < AM; ++mi) {
+        ah[mi] = *reinterpret_cast<const f16x8*>(stage + a_off[0] + mi * 2048);
+        al[mi] = *reinterpret_cast<const f16x8*>(stage + a_off[1] + mi * 2048);
+    }
+#pragma unroll
+    for (int n0 = 0; n0 < AN; n0 += NG) {
+        f16x8 bh[NG], bl[NG];
+#pragma unroll
+        for (int ni = 0; ni < NG; ++ni) {
+            bh[ni] = *reinterpret_cast<const f16x8*>(stage + b_off[0] + (n0 + ni) * 2048);
+            bl[ni] = *reinterpret_cast<const f16x8*>(stage + b_off[1] + (n0 + ni) * 2048);
+        }
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int mi = 0; mi < AM; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < NG; ++ni) {
+                acc[mi][n0 + ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[mi], bh[ni], acc[mi][n0 + ni], 0, 0, 0);
+                acc[mi][n0 + ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[mi], bl[ni], acc[mi][n0 + ni], 0, 0, 0);
+                acc[mi][n0 + ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[mi], bh[ni], acc[mi][n0 + ni], 0, 0, 0);
+            }
+        __builtin_amdgcn_s_setprio(0);
+    }
+}
+
+// Which row of the [M][Cout] output a tile-local row is (-1: none).  Linear tiles are BM
+// consecutive rows; pixel tiles are 8 x 16 patches of one image.
+struct LinearRows {
+    int base, M;
+    __device__ __forceinline__ int operator()(int local) const {
+        const int r = base + local;
+        return r < M ? r : -1;
+    }
+};
+struct PatchRows {
+    int pix0;          // output row of the tile's top-left pixel
+    int W;             // image width in pixels
+    int ymax, xmax;    // valid tile rows / columns (image edge)
+    __device__ __forceinline__ int operator()(int local) const {
+        const int ty = local >> 4, tx = local & 15;
+        return (ty < ymax && tx < xmax) ? pix0 + ty * W + tx : -1;
+    }
+};
+
+// The residual values a lane adds in the epilogue, fetched ahead of time by kernels whose
+// per-workgroup chain of memory round trips would otherwise be exposed.
+template <int BM, int BN, class RM>
+__device__ __forceinline__ void split_residual_prefetch(const SplitKArgs& a, const RM& rm, int tile_n, int wave, int lane,
+                                                        f32x4 (&res)[SplitEpi<BM, BN>::GROUPS][SplitEpi<BM, BN>::PASSES][2]) {
+    using E = SplitEpi<BM, BN>;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int erow = lane / E::L8, ecol = (lane % E::L8) * 8;
+    const int gcol = tile_n * BN + wn * E::WN + ecol;
+    const bool col_ok = gcol < a.Cout;
+    // Every lane issues every load (rows outside the output and columns beyond Cout read a clamped
+    // address and are zeroed afterwards): callers count these loads in their s_waitcnt vmcnt
+    // values, so their number must not depend on the tile.
+    const int safe_col = col_ok ? gcol : 0;
+#pragma unroll
+    for (int mi = 0; mi < E::GROUPS; ++mi)
+#pragma unroll
+        for (int ps = 0; ps < E::PASSES; ++ps) {
+            const int row = rm(wm * (BM / 2) + mi * 32 + ps * E::RPP + erow);
+            const bool ok = row >= 0 && col_ok;
+            const float* rp = a.res + (size_t)(row >= 0 ? row : 0) * a.Cout + safe_col;
+            const f32x4 r0 = *reinterpret_cast<const f32x4*>(rp), r1 = *reinterpret_cast<const f32x4*>(rp + 4);
+            res[mi][ps][0] = ok ? r0 : f32x4{0.f, 0.f, 0.f, 0.f};
+            res[mi][ps][1] = ok ? r1 : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+}
+
+// Epilogue of a 16x16-block tile: transpose each wave's rows through its slice of LDS (32 rows
+// at a time); every lane then owns 8 consecutive channels of a row.
+template <int BM, int BN, bool PREFETCHED, class RM>
+__device__ __forceinline__ void split_epilogue16_rows(const SplitKArgs& a, float* smem, const RM& rm, int tile_n, int wave,
+                                                      int lane, f32x4 (&acc)[BM / 32][BN / 32],
+                                                      f32x4 (*pres)[SplitEpi<BM, BN>::PASSES][2] = nullptr) {
+    using T = SplitTile<BM, BN>;
+    constexpr int WN = T::WN, LDC = T::LDC, AN = T::AN;
+    constexpr int L8 = WN / 8;
+    constexpr int RPP = 64 / L8;
+    constexpr int PASSES = 32 / RPP;
+    const int wm = wave >> 1, wn = wave & 1;
+    float* Cs = smem + wave * (32 * LDC);
+    const int erow = lane / L8, ecol = (lane % L8) * 8;
+    const int gcol = tile_n * BN + wn * WN + ecol;
+    const bool col_ok = gcol < a.Cout;
+    float bias_v[AN];
+#pragma unroll
+    for (int ni = 0; ni < AN; ++ni) {
+        const int col = tile_n * BN + wn * WN + ni * 16 + (lane & 15);
+        bias_v[ni] = (a.bias && col < a.Cout) ? a.bias[col] : 0.f;
+    }
+    f32x4 ps0 = {1.f, 1.f, 1.f, 1.f}, ps1 = ps0, pt0 = {0.f, 0.f, 0.f, 0.f}, pt1 = pt0;
+    const bool post = a.ysplit && a.post_scale && col_ok;
+    if (post) {
+        ps0 = *reinterpret_cast<const f32x4*>(a.post_scale + gcol);
+        ps1 = *reinterpret_cast<const f32x4*>(a.post_scale + gcol + 4);
+        pt0 = *reinterpret_cast<const f32x4*>(a.post_shift + gcol);
+        pt1 = *reinterpret_cast<const f32x4*>(a.post_shift + gcol + 4);
+    }
+#pragma unroll
+    for (int mi = 0; mi < BM / 64; ++mi) {
+        const int lrow0 = wm * (BM / 2) + mi * 32;
+        f32x4 res0[PASSES], res1[PASSES];
+        if (PREFETCHED) {
+#pragma unroll
+            for (int ps = 0; ps < PASSES; ++ps) { res0[ps] = pres[mi][ps][0]; res1[ps] = pres[mi][ps][1]; }
+        } else if (a.res) {
+#pragma unroll
+            for (int ps = 0; ps < PASSES; ++ps) {
+                const int row = rm(lrow0 + ps * RPP + erow);
+                res0[ps] = f32x4{0.f, 0.f, 0.f, 0.f};
+                res1[ps] = res0[ps];
+                if (row >= 0 && col_ok) {
+                    const float* rp = a.res + (size_t)row * a.Cout + gcol;
+                    res0[ps] = *reinterpret_cast<const f32x4*>(rp);
+                    res1[ps] = *reinterpret_cast<const f32x4*>(rp + 4);
+                }
+            }
+        }
+        // The staging slice is private to the wave (LDS operations of a wave execute in order), so
+        // only the first use needs a workgroup barrier: the slice overlays the pipeline stages other
+        // waves may still be reading.
+        if (mi == 0) __syncthreads();
+        else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+            for (int ni = 0; ni < AN; ++ni)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float v = acc[mi * 2 + mb][ni][r] * a.w_inv_scale + bias_v[ni];
+                    if (a.relu) v = fmaxf(v, 0.f);
+                    Cs[(mb * 16 + (lane >> 4) * 4 + r) * LDC + ni * 16 + (lane & 15)] = v;
+                }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int ps = 0; ps < PASSES; ++ps) {
+            const int lrow2 = ps * RPP + erow;
+            const int row = rm(lrow0 + lrow2);
+            f32x4 v0 = *reinterpret_cast<const f32x4*>(&Cs[lrow2 * LDC + ecol]);
+            f32x4 v1 = *reinterpret_cast<const f32x4*>(&Cs[lrow2 * LDC + ecol + 4]);
+            if (a.res) { v0 += res0[ps]; v1 += res1[ps]; }
+            if (row >= 0 && col_ok) {
+                if (a.y32) {
+                    float* yp = a.y32 + (size_t)row * a.Cout + gcol;
+                    // streaming stores: the float32 tensor is far larger than the caches and is next
+                    // read several kernels later (+0.5 % frames/s against plain stores, same box)
+                    __builtin_nontemporal_store(v0, reinterpret_cast<f32x4*>(yp));
+                    __builtin_nontemporal_store(v1, reinterpret_cast<f32x4*>(yp + 4));
+                }
+                if (a.ysplit) {
+                    if (post) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            v0[j] = fmaxf(v0[j] * ps0[j] + pt0[j], 0.f);
+                            v1[j] = fmaxf(v1[j] * ps1[j] + pt1[j], 0.f);
+                        }
+                    }
+                    f16x8 hi, lo;
+                    split8(v0, v1, hi, lo);
+                    uint8_t* sp = a.ysplit + (size_t)row * a.Cout * 4 + split_offset(gcol);
+                    *reinterpret_cast<f16x8*>(sp) = hi;
+                    *reinterpret_cast<f16x8*>(sp + 64) = lo;
+                }
+            }
+        }
+    }
+}
+
+// the same for a tile of BM consecutive output rows
+template <int BM, int BN, bool PREFETCHED = false>
+__device__ __forceinline__ void split_epilogue16(const SplitKArgs& a, float* smem, int tile_m, int tile_n, int wave,
+                                                 int lane, f32x4 (&acc)[BM / 32][BN / 32],
+                                                 f32x4 (*pres)[SplitEpi<BM, BN>::PASSES][2] = nullptr) {
+    const LinearRows rm{tile_m * BM, a.M};
+    split_epilogue16_rows<BM, BN, PREFETCHED>(a, smem, rm, tile_n, wave, lane, acc, pres);
+}
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// Workgroup barrier for the multi-stage LDS-DMA loops.  __syncthreads() carries fences that make
+// the compiler drain every vector-memory operation (s_waitcnt vmcnt(0)) while LDS-DMA is in
+// flight, which turns a three- or four-stage pipeline into a two-stage one; here only this wave's
+// LDS operations are drained, and LDS-DMA completion is the caller's business (wait_vmcnt before
+// the barrier).
+__device__ __forceinline__ void pipeline_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
+}  // namespace fd
