@@ -1,0 +1,64 @@
+#!/usr/bin/env python3
+"""Rates of the kernels either side of the detector (the rows that follow the hot path): the
+command-line front end (colour swap + resize of decoded frames, detection on the resized frames)
+and the crop hand-off (stick_boxes + resize_pad tiles for the recogniser), on device-resident
+frames.  Algorithmic bytes: source pixels read once + destination pixels written once.
+
+    python tools/frontend_bench.py [frames=32]
+"""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from facedetection_amd import ops  # noqa: E402
+from facedetection_amd.detection import Detector  # noqa: E402
+from facedetection_amd.synthetic import synthetic_image  # noqa: E402
+
+
+def timed(fn, reps):
+    fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / reps
+
+
+def main():
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 32
+    torch.cuda.set_device(0)
+    frames = torch.from_numpy(np.stack([synthetic_image(1080, 1920, seed=s) for s in range(n)])).cuda()
+    out = {}
+    # resize as the command-line loop does it (short side 600, long side capped at 1000)
+    scale = 1000.0 / 1920.0
+    t = timed(lambda: ops.resize_bilinear(frames, scale, scale), 10)
+    small = ops.resize_bilinear(frames, scale, scale)
+    moved = frames.numel() + small.numel()
+    out["resize_1080p_to_%dx%d" % (small.shape[1], small.shape[2])] = {
+        "frames_per_s": round(n / t, 1), "GB_per_s": round(moved / t / 1e9, 1)}
+    # crop hand-off: 16 boxes per frame -> 112x112 tiles
+    rng = np.random.default_rng(0)
+    boxes = np.zeros((16, 5), dtype=np.float64)
+    boxes[:, 0] = rng.uniform(0, 1500, 16); boxes[:, 1] = rng.uniform(0, 800, 16)
+    boxes[:, 2] = boxes[:, 0] + rng.uniform(60, 400, 16); boxes[:, 3] = boxes[:, 1] + rng.uniform(60, 270, 16)
+    one = frames[0]
+    t = timed(lambda: ops.crop_resize_pad(one, boxes, (112, 112)), 50)
+    src = float(np.sum((boxes[:, 2] - boxes[:, 0]) * 1.2 * (boxes[:, 3] - boxes[:, 1]) * 1.2 * 3))
+    out["crop_16_boxes_to_112x112"] = {"us_per_frame": round(t * 1e6, 1),
+                                       "GB_per_s": round((src + 16 * 112 * 112 * 3) / t / 1e9, 2)}
+    # the command-line loop end to end on decoded 1080p frames (resize + detect + map back)
+    det = Detector("synthetic:0", 0)
+    t = timed(lambda: det.detect_scaled_batch(frames[:8], thresh=0.5), 5)
+    out["cli_loop_1080p_batch8"] = {"frames_per_s": round(8 / t, 1)}
+    det.close()
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()
