@@ -357,12 +357,19 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) void conv_split_gld
     // this workgroup's K-steps: kb .. kb + nk - 1 (everything unless the launch splits K)
     const int kb = ks * a.kchunk;
     const int nk = min(a.K / SBK, kb + a.kchunk) - kb;
-    int kh, kw, coff;
+    // Order of the K-steps: 32-channel chunk outermost, filter taps inside.  All taps of a chunk
+    // read nearly the same activation rows (shifted by one pixel or one image row), 128 bytes
+    // each, so a workgroup's working set between re-uses is a few dozen KB and stays in L2; with
+    // the taps outermost every tap streamed the rows' full channel depth and a 3x3 layer fetched
+    // its input nine times from memory (PMC: 612 MB for a 67 MB input).
+    const int ntaps = a.K / a.Cin, cchunks = a.Cin / SBK;
+    int kh, kw, coff, tapi;
     {
-        const int tap = (kb * SBK) / a.Cin;
-        coff = kb * SBK - tap * a.Cin;
-        kh = tap / a.KW;
-        kw = tap - kh * a.KW;
+        const int chunk = kb / ntaps;
+        tapi = kb - chunk * ntaps;
+        coff = chunk * SBK;
+        kh = tapi / a.KW;
+        kw = tapi - kh * a.KW;
     }
 
     // Per-lane offsets of the activation rows change only with the filter tap (validity of the
@@ -388,12 +395,13 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) void conv_split_gld
         _Pragma("unroll") for (int i = 0; i < GB; ++i)                                            \
             __builtin_amdgcn_raw_ptr_buffer_load_lds(                                             \
                 wr, (__attribute__((address_space(3))) void*)(sa_ + BM * 32 + (wave + WAVES * i) * 256), 16, \
-                bvo[i], (kb + (KT)) * 128, 0, 0);                                                        \
-        coff += SBK;                                                                              \
-        if (coff >= a.Cin) {                                                                      \
-            coff = 0;                                                                             \
-            if (++kw == a.KW) { kw = 0; ++kh; }                                                   \
+                bvo[i], (tapi * cchunks + (coff >> 5)) * 128, 0, 0);                              \
+        if (ntaps > 1) {                                                                          \
+            if (++tapi == ntaps) { tapi = 0; kh = 0; kw = 0; coff += SBK; }                       \
+            else if (++kw == a.KW) { kw = 0; ++kh; }                                              \
             FD_TAP();                                                                             \
+        } else {                                                                                  \
+            coff += SBK;                                                                          \
         }                                                                                         \
     } while (0)
 
