@@ -156,24 +156,29 @@ def main():
     for _ in range(args.warmup):
         step()
     barrier()
+    # Per-kernel durations come from one extra, untimed step on a single stream with every kernel
+    # group bracketed by HIP events (on an otherwise idle chip: with more than one stream a launch
+    # of the timed region shares the GPU with the other stream's kernels and lasts longer).  It
+    # also tells which kernel dominates; inside the timed region only that kernel is bracketed,
+    # so the other ~110 launches per micro-batch do not pay for two event records each.
+    iso_rows, dom_name = [], None
     if not args.no_profile:
-        profiling.begin()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        outs = step()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    rows = [] if args.no_profile else profiling.end()
-    # With more than one stream a launch shares the GPU with the other stream's kernels, so its
-    # event-bracketed duration is longer than on an idle chip.  One extra, untimed step on a single
-    # stream gives the isolated per-kernel durations next to the ones of the timed region.
-    iso_rows = []
-    if rows and args.streams > 1:
         profiling.begin()
         for i in range(0, args.frames, B):
             pipe.detectors[0].detect_batch_device(frames[i:i + B])
         torch.cuda.synchronize()
         iso_rows = profiling.end()
+        conv = [r for r in iso_rows if r["kernel"].startswith("conv_")]
+        dom_name = max(conv, key=lambda r: r["ms"])["kernel"] if conv else None
+        barrier()
+    if dom_name:
+        profiling.begin(only=dom_name)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        outs = step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    rows = profiling.end() if dom_name else []
 
     if distributed:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
@@ -212,8 +217,8 @@ def main():
                        "frames_start": "pinned host memory (PCIe upload timed)" if args.from_host else "HBM"},
         }
         if rows:
-            conv = [r for r in rows if r["kernel"].startswith("conv_")]
-            dom = max(conv, key=lambda r: r["ms"])
+            dom = rows[0]
+            conv = [r for r in iso_rows if r["kernel"].startswith("conv_")]
             tf = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
             # split precision executes 3 f16 MFMA FLOPs per algorithmic FLOP, so the ceiling for
             # ALGORITHMIC FLOP/s on that path is the dense f16 MFMA peak / 3
@@ -228,25 +233,25 @@ def main():
                 "peak_note": ("dense f16 MFMA peak 2500 TFLOP/s / 3 MFMAs per product" if split
                               else "dense fp32 MFMA peak"),
                 "launches": dom["launches"], "avg_launch_ms": round(dom["ms"] / dom["launches"], 4),
-                "all_conv_tflops": round(sum(r["flops"] for r in conv) / (sum(r["ms"] for r in conv) * 1e-3) / 1e12, 3),
+                "measured": "HIP events around every launch of this kernel inside the timed region",
                 "pipeline_tflops": round(GFLOP_PER_FRAME * fps / 1e3, 3),
                 # the reference computes in float32 and this path delivers float32-grade results, so the
                 # float32 matrix peak is the ceiling a plain fp32 implementation would have had
                 "achieved_over_fp32_matrix_peak": round(tf / PEAK_FP32_MATRIX_TFLOPS, 4) if split else None,
             }
-            if iso_rows:
-                iso = [r for r in iso_rows if r["kernel"] == dom["kernel"]][0]
-                itf = iso["flops"] / (iso["ms"] * 1e-3) / 1e12
-                line["roofline"]["isolated"] = {
-                    "achieved": round(itf, 3), "frac": round(itf / peak, 4),
-                    "avg_launch_ms": round(iso["ms"] / iso["launches"], 4),
-                    "note": "same kernel in one extra untimed step on a single stream; in the timed region "
-                            "its launches overlap the other stream's kernels, which lengthens each launch "
-                            "while raising whole-pipeline throughput"}
-            line["kernels"] = [
+            iso = [r for r in iso_rows if r["kernel"] == dom["kernel"]][0]
+            itf = iso["flops"] / (iso["ms"] * 1e-3) / 1e12
+            line["roofline"]["isolated"] = {
+                "achieved": round(itf, 3), "frac": round(itf / peak, 4),
+                "avg_launch_ms": round(iso["ms"] / iso["launches"], 4),
+                "all_conv_tflops": round(sum(r["flops"] for r in conv) / (sum(r["ms"] for r in conv) * 1e-3) / 1e12, 3),
+                "note": "same kernel in one extra untimed step on a single stream; in the timed region "
+                        "its launches overlap the other stream's kernels, which lengthens each launch "
+                        "while raising whole-pipeline throughput"}
+            line["kernels_single_stream_step"] = [
                 {"kernel": r["kernel"], "launches": r["launches"], "ms": round(r["ms"], 3),
                  "tflops": round(r["flops"] / (r["ms"] * 1e-3) / 1e12, 3) if r["flops"] else None,
-                 "gbs": round(r["bytes"] / (r["ms"] * 1e-3) / 1e9, 1)} for r in sorted(rows, key=lambda r: -r["ms"])]
+                 "gbs": round(r["bytes"] / (r["ms"] * 1e-3) / 1e9, 1)} for r in sorted(iso_rows, key=lambda r: -r["ms"])]
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line), flush=True)

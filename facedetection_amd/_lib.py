@@ -59,6 +59,7 @@ SIGNATURES = {
     "fd_ctx_destroy": (None, [vp]),
     "fd_ctx_scratch_bytes": (C.c_int64, [vp]),
     "fd_profile_begin": (C.c_int, []),
+    "fd_profile_begin_only": (C.c_int, [C.c_char_p]),
     "fd_profile_end": (C.c_int, [C.POINTER(ProfileRow), C.c_int, C.POINTER(C.c_int)]),
     "fd_generate_anchors": (C.c_int, [C.c_double, c_f64p, C.c_int, c_f64p, C.c_int, c_f64p]),
     "fd_bbox_pred_f64": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, vp, vp]),

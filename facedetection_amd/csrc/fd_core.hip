@@ -54,6 +54,7 @@ struct ProfRec {
 };
 struct Profiler {
     bool active = false;
+    std::string only;                    // non-empty: bracket this kernel group only
     std::vector<std::string> names;
     std::vector<ProfRec> recs;
     std::vector<hipEvent_t> pool;
@@ -74,6 +75,7 @@ static hipEvent_t prof_event() {
 }
 
 int prof_open(hipStream_t stream, const char* kernel, double flops, double bytes) {
+    if (!g_prof.only.empty() && g_prof.only != kernel) return -1;
     int id = -1;
     for (size_t i = 0; i < g_prof.names.size(); ++i)
         if (g_prof.names[i] == kernel) id = (int)i;
@@ -99,6 +101,14 @@ void prof_close(hipStream_t stream, int token) { (void)hipEventRecord(g_prof.rec
 extern "C" {
 
 int fd_profile_begin(void) {
+    fd::g_prof.only.clear();
+    fd::g_prof.active = true;
+    return FD_OK;
+}
+
+int fd_profile_begin_only(const char* kernel) {
+    FD_REQUIRE(kernel && kernel[0], "fd_profile_begin_only: empty kernel name");
+    fd::g_prof.only = kernel;
     fd::g_prof.active = true;
     return FD_OK;
 }

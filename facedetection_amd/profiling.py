@@ -4,8 +4,12 @@ import ctypes as C
 from . import _lib
 
 
-def begin():
-    _lib.check(_lib.lib().fd_profile_begin())
+def begin(only=None):
+    """Starts bracketing every kernel group, or only the group named ``only``."""
+    if only:
+        _lib.check(_lib.lib().fd_profile_begin_only(only.encode("ascii")))
+    else:
+        _lib.check(_lib.lib().fd_profile_begin())
 
 
 def end(capacity=64):

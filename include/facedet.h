@@ -56,6 +56,9 @@ typedef struct fd_profile_row {
     double bytes;
 } fd_profile_row;
 int fd_profile_begin(void);
+/* The same, bracketing only the kernel group called `kernel` (every event costs launch time; a
+ * benchmark that needs one kernel's durations inside its timed region asks for that one only). */
+int fd_profile_begin_only(const char* kernel);
 int fd_profile_end(fd_profile_row* rows_host, int capacity, int* n_rows);
 
 /* Box arithmetic ------------------------------------------------------------ */
