@@ -153,6 +153,8 @@ __device__ __forceinline__ void split_epilogue16_rows(const SplitKArgs& a, float
         bias_v[ni] = (a.bias && col < a.Cout) ? a.bias[col] : 0.f;
     }
     f32x4 ps0 = {1.f, 1.f, 1.f, 1.f}, ps1 = ps0, pt0 = {0.f, 0.f, 0.f, 0.f}, pt1 = pt0;
+    // float32 outputs larger than the memory-side cache are written with streaming stores
+    const bool stream_out = (long long)a.M * a.Cout > (80ll << 20);
     const bool post = a.ysplit && a.post_scale && col_ok;
     if (post) {
         ps0 = *reinterpret_cast<const f32x4*>(a.post_scale + gcol);
@@ -208,8 +210,13 @@ __device__ __forceinline__ void split_epilogue16_rows(const SplitKArgs& a, float
                     float* yp = a.y32 + (size_t)row * a.Cout + gcol;
                     // streaming stores: the float32 tensor is far larger than the caches and is next
                     // read several kernels later (+0.5 % frames/s against plain stores, same box)
-                    __builtin_nontemporal_store(v0, reinterpret_cast<f32x4*>(yp));
-                    __builtin_nontemporal_store(v1, reinterpret_cast<f32x4*>(yp + 4));
+                    if (stream_out) {
+                        __builtin_nontemporal_store(v0, reinterpret_cast<f32x4*>(yp));
+                        __builtin_nontemporal_store(v1, reinterpret_cast<f32x4*>(yp + 4));
+                    } else {
+                        *reinterpret_cast<f32x4*>(yp) = v0;
+                        *reinterpret_cast<f32x4*>(yp + 4) = v1;
+                    }
                 }
                 if (a.ysplit) {
                     if (post) {
