@@ -18,25 +18,47 @@ def shard_indices(n_frames, rank, world):
 def gather_detections(dets, counts, rank=0, world=1, force_collective=False):
     """dets [F,R,5] float32 and counts [F] int32 of this rank's frames (frame j of rank r is
     global frame j*world + r) -> on every rank, a list over GLOBAL frame order of float32
-    [n_i,5] arrays, ready for an order-dependent consumer such as a SORT tracker."""
+    [n_i,5] arrays, ready for an order-dependent consumer such as a SORT tracker.
+
+    Ranks may hold different numbers of frames (a frame count that is not a multiple of the
+    world size gives the first ranks one frame more): the per-rank frame counts are exchanged
+    first and every rank pads its tensors to the longest shard before the two gathers, so all
+    collectives see equal sizes on every rank."""
     F, R = int(dets.shape[0]), int(dets.shape[1])
     if world == 1 and not force_collective:
         d, c = dets.cpu().numpy(), counts.cpu().numpy()
         return [d[i, :c[i]].copy() for i in range(F)]
     import torch.distributed as dist
-    # counts first (fixed size), then the rows trimmed to the longest list in the job
-    all_counts = [torch.empty_like(counts) for _ in range(world)]
-    dist.all_gather(all_counts, counts.contiguous())
-    max_n = max(1, int(torch.stack(all_counts).max().item()))
-    payload = dets[:, :max_n, :].contiguous()
+    dev = dets.device
+    # 1. frames per rank
+    mine = torch.tensor([F], dtype=torch.int64, device=dev)
+    all_f = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(all_f, mine)
+    fs = [int(t.item()) for t in all_f]
+    n_frames, f_max = sum(fs), max(fs)
+    for r in range(world):
+        if fs[r] != len(range(r, n_frames, world)):
+            raise ValueError("rank %d holds %d frames; frame i -> rank i mod %d of %d frames gives %d"
+                             % (r, fs[r], world, n_frames, len(range(r, n_frames, world))))
+    if f_max == 0:
+        return []
+    # 2. detections per frame, padded to the longest shard
+    c_pad = torch.zeros((f_max,), dtype=torch.int32, device=dev)
+    c_pad[:F] = counts.to(torch.int32)
+    all_counts = [torch.empty_like(c_pad) for _ in range(world)]
+    dist.all_gather(all_counts, c_pad)
+    # 3. the rows, trimmed to the longest list in the job
+    max_n = min(R, max(1, int(torch.stack(all_counts).max().item())))
+    payload = torch.zeros((f_max, max_n, 5), dtype=torch.float32, device=dev)
+    payload[:F] = dets[:, :max_n, :]
     all_dets = [torch.empty_like(payload) for _ in range(world)]
     dist.all_gather(all_dets, payload)
     cs = [c.cpu().numpy() for c in all_counts]
     ds = [d.cpu().numpy() for d in all_dets]
     out = []
-    for j in range(F):
-        for r in range(world):
-            out.append(ds[r][j, :cs[r][j]].copy())
+    for i in range(n_frames):
+        r, j = i % world, i // world
+        out.append(ds[r][j, :cs[r][j]].copy())
     return out
 
 

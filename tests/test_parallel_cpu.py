@@ -4,6 +4,7 @@ import os
 import socket
 
 import numpy as np
+import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -33,11 +34,12 @@ def _worker(rank, world, port, n_frames, out_dir):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     mine = shard_indices(n_frames, rank, world)
-    d = np.stack([_fake_detections(i)[0] for i in mine])
+    d = np.stack([_fake_detections(i)[0] for i in mine]) if mine else np.zeros((0, 10, 5), np.float32)
     c = np.array([_fake_detections(i)[1] for i in mine], np.int32)
     out = gather_detections(torch.from_numpy(d), torch.from_numpy(c), rank, world)
-    np.save(os.path.join(out_dir, "rank%d.npy" % rank), np.concatenate([o.reshape(-1) for o in out]))
-    np.save(os.path.join(out_dir, "len%d.npy" % rank), np.array([len(o) for o in out]))
+    np.save(os.path.join(out_dir, "rank%d.npy" % rank),
+            np.concatenate([o.reshape(-1) for o in out] + [np.zeros(0, np.float32)]))
+    np.save(os.path.join(out_dir, "len%d.npy" % rank), np.array([len(o) for o in out], dtype=np.int64))
     dist.destroy_process_group()
 
 
@@ -55,13 +57,15 @@ def test_single_rank_gather_is_a_trim():
     np.testing.assert_array_equal(out[3], d[3, :c[3]])
 
 
-def test_two_rank_gloo_gather_restores_global_order(tmp_path):
-    world, n_frames = 2, 12
+@pytest.mark.parametrize("world,n_frames", [(2, 12), (2, 13), (3, 14), (3, 2), (2, 0)])
+def test_gloo_gather_restores_global_order(tmp_path, world, n_frames):
+    """Even shards, shards of unequal length (13 frames on 2 ranks, 14 on 3), fewer frames than
+    ranks, and no frames at all."""
     port = _free_port()
     mp.spawn(_worker, args=(world, port, n_frames, str(tmp_path)), nprocs=world, join=True)
     expect = [_fake_detections(i) for i in range(n_frames)]
-    flat = np.concatenate([d[:n].reshape(-1) for d, n in expect])
-    lens = np.array([n for _, n in expect])
+    flat = np.concatenate([d[:n].reshape(-1) for d, n in expect] + [np.zeros(0, np.float32)])
+    lens = np.array([n for _, n in expect], dtype=np.int64)
     for r in range(world):
         np.testing.assert_array_equal(np.load(tmp_path / ("rank%d.npy" % r)), flat)
         np.testing.assert_array_equal(np.load(tmp_path / ("len%d.npy" % r)), lens)
