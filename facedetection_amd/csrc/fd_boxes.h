@@ -51,8 +51,9 @@ int postprocess_run(fd_ctx* ctx, const float* rois, int roi_stride, const float*
 int roipool_nhwc(const float* data, int batch, int channels, int height, int width, const float* rois, int num_rois,
                  int pooled_h, int pooled_w, float spatial_scale, float* out, hipStream_t stream);
 // Pooling written directly as split(relu(max * bn_scale[c] + bn_shift[c])) (channels % 32 == 0).
+// `clamped`: device counter of values outside the fp16 range met while splitting, or NULL.
 int roipool_nhwc_split(const float* data, int batch, int channels, int height, int width, const float* rois,
                        int num_rois, int pooled_h, int pooled_w, float spatial_scale, const float* bn_scale,
-                       const float* bn_shift, void* out_split, hipStream_t stream);
+                       const float* bn_shift, void* out_split, unsigned* clamped, hipStream_t stream);
 
 }  // namespace fd

@@ -981,10 +981,11 @@ __global__ __launch_bounds__(128) void roipool_nhwc_split_kernel(const float* __
                                                                 int W, const float* __restrict__ rois, int PH, int PW,
                                                                 float scale, const float* __restrict__ bn_scale,
                                                                 const float* __restrict__ bn_shift,
-                                                                uint8_t* __restrict__ out) {
+                                                                uint8_t* __restrict__ out, unsigned* __restrict__ clamped) {
     const int bin = blockIdx.x, n = blockIdx.y;
     const RoiBin r = roi_bin(rois + (size_t)n * 5, scale, bin / PW, bin % PW, PH, PW, H, W, batch);
     uint8_t* o = out + ((size_t)n * PH * PW + bin) * C * 4;
+    unsigned bad = 0;
     for (int c8 = threadIdx.x; c8 < C / 8; c8 += 128) {
         f32x4 m0 = {0.f, 0.f, 0.f, 0.f}, m1 = m0;
         if (!r.empty) {
@@ -1010,15 +1011,16 @@ __global__ __launch_bounds__(128) void roipool_nhwc_split_kernel(const float* __
             m1[j] = fmaxf(__builtin_fmaf(m1[j], s1[j], t1[j]), 0.f);
         }
         f16x8 hi, lo;
-        split8(m0, m1, hi, lo);
+        split8(m0, m1, hi, lo, bad);
         uint8_t* sp = o + split_offset(c8 * 8);
         *reinterpret_cast<f16x8*>(sp) = hi;
         *reinterpret_cast<f16x8*>(sp + 64) = lo;
     }
+    split_report(clamped, bad);
 }
 
 int roipool_nhwc_split(const float* data, int batch, int C, int H, int W, const float* rois, int num_rois, int PH,
-                       int PW, float scale, const float* bn_scale, const float* bn_shift, void* out,
+                       int PW, float scale, const float* bn_scale, const float* bn_shift, void* out, unsigned* clamped,
                        hipStream_t stream) {
     FD_REQUIRE(data && rois && out && bn_scale && bn_shift, "roipool: NULL argument");
     FD_REQUIRE(C % 32 == 0 && C > 0, "roipool (split output): channel count %d must be a multiple of 32", C);
@@ -1026,7 +1028,7 @@ int roipool_nhwc_split(const float* data, int batch, int C, int H, int W, const 
     if (num_rois <= 0) return FD_OK;
     ProfScope scope(stream, "roipool", 0.0, 2.0 * 4.0 * (double)num_rois * PH * PW * C);
     hipLaunchKernelGGL(roipool_nhwc_split_kernel, dim3(PH * PW, num_rois), dim3(128), 0, stream, data, batch, C, H, W,
-                       rois, PH, PW, scale, bn_scale, bn_shift, static_cast<uint8_t*>(out));
+                       rois, PH, PW, scale, bn_scale, bn_shift, static_cast<uint8_t*>(out), clamped);
     FD_LAUNCH_CHECK();
     return FD_OK;
 }

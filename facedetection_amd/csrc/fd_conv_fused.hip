@@ -153,6 +153,7 @@ __global__ __launch_bounds__(256, 2) void conv_tail_fused_kernel(SplitKArgs a, S
     // columns are exactly one K-step of the 1x1: K-step index = wn)
     char* aimg = reinterpret_cast<char*>(smem) + CS_BYTES;
     {
+        unsigned bad2 = 0;
         constexpr int LDC = T::LDC;
         float* Cs = smem + wave * (32 * LDC);
         const int erow = lane / E::L8, ecol = (lane % E::L8) * 8;
@@ -178,13 +179,14 @@ __global__ __launch_bounds__(256, 2) void conv_tail_fused_kernel(SplitKArgs a, S
                 const f32x4 v0 = *reinterpret_cast<const f32x4*>(&Cs[lrow2 * LDC + ecol]);
                 const f32x4 v1 = *reinterpret_cast<const f32x4*>(&Cs[lrow2 * LDC + ecol + 4]);
                 f16x8 hi, lo;
-                split8(v0, v1, hi, lo);
+                split8(v0, v1, hi, lo, bad2);
                 char* kstep = aimg + wn * (BM * 128);
                 const int off = row * 128 + (((ecol >> 3) ^ ((row >> 1) & 7)) * 16);
                 *reinterpret_cast<f16x8*>(kstep + off) = hi;
                 *reinterpret_cast<f16x8*>(kstep + (off ^ 64)) = lo;      // lo chunk = hi chunk + 4
             }
         }
+        split_report(c.clamped, bad2);
     }
 
     // ---- phase 3: the 1x1 convolution, 64 output channels at a time ----
@@ -264,7 +266,7 @@ int conv_tail_fused_forward(const SplitConvParams& p2, const SplitConvParams& p3
     a.pre_scale = a.pre_shift = nullptr; a.w_inv_scale = p2.w_inv_scale;
     a.H = h; a.W = w; a.Cin = 64; a.Ho = h; a.Wo = w; a.Cout = 64; a.KW = 3; a.stride = 1; a.pad = 1; a.K = s2.k();
     a.M = (int)m_ll; a.relu = 1; a.tiles_n = 1;
-    a.ksplit = 1; a.kchunk = a.K / SBK; a.partial = nullptr;
+    a.ksplit = 1; a.kchunk = a.K / SBK; a.partial = nullptr; a.clamped = out.clamped;
     c = a;
     c.x = nullptr; c.w = static_cast<const uint8_t*>(p3.w); c.bias = p3.bias; c.res = residual; c.y32 = out.y32;
     c.ysplit = static_cast<uint8_t*>(out.ysplit); c.post_scale = out.post_scale; c.post_shift = out.post_shift;
@@ -403,6 +405,7 @@ __global__ __launch_bounds__(256, 2) void unit_fused_kernel(UnitFusedArgs u) {
     for (int nf = 0; nf < 4; ++nf)
 #pragma unroll
         for (int f = 0; f < 3; ++f) acc0[nf][f] = f32x4{0.f, 0.f, 0.f, 0.f};
+    unsigned bad = 0;          // values outside the fp16 range met while splitting (input, t1, t2)
 
     FD_WDMA(w1r, wvo1, 0, 0);
     FD_XLOAD(0);
@@ -422,9 +425,9 @@ __global__ __launch_bounds__(256, 2) void unit_fused_kernel(UnitFusedArgs u) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     _Float16 h_, l_;
-                    split_f32_relu(ra[f][0][j] * s0[j] + t0[j], h_, l_);
+                    split_f32_relu(ra[f][0][j] * s0[j] + t0[j], h_, l_, bad);
                     bh[f][j] = h_; bl[f][j] = l_;
-                    split_f32_relu(ra[f][1][j] * s1[j] + t1[j], h_, l_);
+                    split_f32_relu(ra[f][1][j] * s1[j] + t1[j], h_, l_, bad);
                     bh[f][4 + j] = h_; bl[f][4 + j] = l_;
                 }
         }
@@ -482,7 +485,7 @@ __global__ __launch_bounds__(256, 2) void unit_fused_kernel(UnitFusedArgs u) {
                     float v = acc0[nf][f][j] * a1.w_inv_scale + b[j];
                     if (!pval[f]) v = 0.f;                  // zero padding of the 3x3 applies to t1
                     _Float16 h_, l_;
-                    split_f32_relu(v, h_, l_);
+                    split_f32_relu(v, h_, l_, bad);
                     h4[j] = h_; l4[j] = l_;
                 }
                 const int chunk = (nf & 1) * 2 + (fh >> 1);
@@ -577,7 +580,7 @@ __global__ __launch_bounds__(256, 2) void unit_fused_kernel(UnitFusedArgs u) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     _Float16 h_, l_;
-                    split_f32_relu(acc1[nf][pf][j] * a2.w_inv_scale + b[j], h_, l_);
+                    split_f32_relu(acc1[nf][pf][j] * a2.w_inv_scale + b[j], h_, l_, bad);
                     h4[j] = h_; l4[j] = l_;
                 }
                 const int chunk = (nf & 1) * 2 + (fh >> 1);
@@ -587,6 +590,8 @@ __global__ __launch_bounds__(256, 2) void unit_fused_kernel(UnitFusedArgs u) {
             }
         }
     }
+
+    split_report(c.clamped, bad);
 
     // ---- phase 3: the last 1x1 convolution, 64 output channels at a time (as conv_tail_fused_kernel) ----
     const char* sbase = sbytes;
@@ -646,6 +651,7 @@ int unit_fused_forward(const SplitConvParams& p1, const SplitConvParams& p2, con
     a.pre_scale = pre_scale; a.pre_shift = pre_shift; a.w_inv_scale = p1.w_inv_scale;
     a.H = h; a.W = w; a.Cin = 256; a.Ho = h; a.Wo = w; a.Cout = 64; a.KW = 1; a.stride = 1; a.pad = 0; a.K = 256;
     a.M = (int)m_ll; a.relu = 1; a.tiles_n = 1; a.ksplit = 1; a.kchunk = a.K / SBK; a.partial = nullptr;
+    a.clamped = out.clamped;
     u.c1 = a;
     u.c2 = a;
     u.c2.x = nullptr; u.c2.w = static_cast<const uint8_t*>(p2.w); u.c2.bias = p2.bias; u.c2.pre_scale = u.c2.pre_shift = nullptr;
@@ -783,6 +789,7 @@ __global__ __launch_bounds__(256, 2) void unit_proj_fused_kernel(UnitProjArgs u)
     }
     wait_vmcnt<0>();
     __syncthreads();
+    unsigned bad = 0;           // values outside the fp16 range met while splitting t1 and t2
     f32x4 acc0[4][3];
 #pragma unroll
     for (int nf = 0; nf < 4; ++nf)
@@ -837,7 +844,7 @@ __global__ __launch_bounds__(256, 2) void unit_proj_fused_kernel(UnitProjArgs u)
                     float v = acc0[nf][f][j] * a1.w_inv_scale + b[j];
                     if (!pval[f]) v = 0.f;                  // zero padding of the 3x3 applies to t1
                     _Float16 h_, l_;
-                    split_f32_relu(v, h_, l_);
+                    split_f32_relu(v, h_, l_, bad);
                     h4[j] = h_; l4[j] = l_;
                 }
                 const int chunk = (nf & 1) * 2 + (fh >> 1);
@@ -917,7 +924,7 @@ __global__ __launch_bounds__(256, 2) void unit_proj_fused_kernel(UnitProjArgs u)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     _Float16 h_, l_;
-                    split_f32_relu(acc1[nf][pf][j] * a2.w_inv_scale + b[j], h_, l_);
+                    split_f32_relu(acc1[nf][pf][j] * a2.w_inv_scale + b[j], h_, l_, bad);
                     h4[j] = h_; l4[j] = l_;
                 }
                 const int chunk = (nf & 1) * 2 + (fh >> 1);
@@ -927,6 +934,7 @@ __global__ __launch_bounds__(256, 2) void unit_proj_fused_kernel(UnitProjArgs u)
             }
         }
     }
+    split_report(c.clamped, bad);
     pipeline_barrier();
 
     // ---- phase 3: y = W3 t2 + Wsc act ----
@@ -1037,7 +1045,7 @@ __global__ __launch_bounds__(256, 2) void unit_proj_fused_kernel(UnitProjArgs u)
 
 int unit_proj_fused_forward(const SplitConvParams& p1, const SplitConvParams& p2, const SplitConvParams& p3,
                             const SplitConvParams& psc, const void* act, int batch, int h, int w, float* y32,
-                            hipStream_t stream, bool* taken) {
+                            unsigned* clamped, hipStream_t stream, bool* taken) {
     *taken = false;
     const ConvShape &s1 = p1.s, &s2 = p2.s, &s3 = p3.s, &ss = psc.s;
     if (!(s1.cin == 64 && s1.cout == 64 && s1.kh == 1 && s1.kw == 1 && s1.stride == 1 && s1.pad == 0 && p1.relu &&
@@ -1056,7 +1064,7 @@ int unit_proj_fused_forward(const SplitConvParams& p1, const SplitConvParams& p2
     a.bias = p1.bias; a.res = nullptr; a.y32 = nullptr; a.ysplit = nullptr; a.post_scale = a.post_shift = nullptr;
     a.pre_scale = a.pre_shift = nullptr; a.w_inv_scale = p1.w_inv_scale;
     a.H = h; a.W = w; a.Cin = 64; a.Ho = h; a.Wo = w; a.Cout = 64; a.KW = 1; a.stride = 1; a.pad = 0; a.K = 64;
-    a.M = (int)m_ll; a.relu = 1; a.tiles_n = 1; a.ksplit = 1; a.kchunk = 2; a.partial = nullptr;
+    a.M = (int)m_ll; a.relu = 1; a.tiles_n = 1; a.ksplit = 1; a.kchunk = 2; a.partial = nullptr; a.clamped = clamped;
     u.c1 = a;
     u.c2 = a;
     u.c2.x = nullptr; u.c2.w = static_cast<const uint8_t*>(p2.w); u.c2.bias = p2.bias; u.c2.w_inv_scale = p2.w_inv_scale;
@@ -1099,6 +1107,7 @@ struct StemPoolArgs {
     const float* post_shift;
     float* y32;              // pooled float32 [B][Hp][Wp][64] or NULL
     uint8_t* ysplit;         // pooled split output
+    unsigned* clamped;       // device counter of out-of-range values met while splitting, or NULL
     float w_inv_scale;
     int H, W, Ho, Wo, Hp, Wp, tiles_y, tiles_x;
     int Wpad;                // columns per staged row: 3 zero columns, W pixels, zero columns up to Wpad
@@ -1240,6 +1249,7 @@ __global__ __launch_bounds__(256, OCC) void stem_pool_kernel(StemPoolArgs a, uns
     __syncthreads();
 
     // pooling: one item = 8 channels of one pooled pixel
+    unsigned bad = 0;
     for (int item = tid; item < PH * PW * (COUT / 8); item += 256) {
         const int cg = item & 7, pp = item >> 3;
         const int ppy = pp / PW, ppx = pp - ppy * PW;
@@ -1277,11 +1287,12 @@ __global__ __launch_bounds__(256, OCC) void stem_pool_kernel(StemPoolArgs a, uns
             }
         }
         f16x8 hi, lo;
-        split8(m0, m1, hi, lo);
+        split8(m0, m1, hi, lo, bad);
         uint8_t* sp = a.ysplit + orow * COUT * 4 + split_offset(c);
         *reinterpret_cast<f16x8*>(sp) = hi;
         *reinterpret_cast<f16x8*>(sp + 64) = lo;
     }
+    split_report(a.clamped, bad);
 #endif
 }
 
@@ -1291,7 +1302,7 @@ __global__ __launch_bounds__(256, OCC) void stem_pool_kernel(StemPoolArgs a, uns
 constexpr int STEM_PH = 5, STEM_PW = 11, STEM_BM = 256, STEM_OCC = 2;
 int stem_pool_forward(const SplitConvParams& p, const void* staged_planar, int batch, int h, int w,
                       const float* post_scale, const float* post_shift, float* y32, void* ysplit,
-                      hipStream_t stream) {
+                      unsigned* clamped, hipStream_t stream) {
     const ConvShape& s = p.s;
     FD_REQUIRE(staged_planar && p.w && ysplit, "stem+pool: NULL tensor");
     FD_REQUIRE(s.cin == 4 && s.kwp == 8 && s.kh == 7 && s.kw == 7 && s.stride == 2 && s.pad == 3 && s.cout == 64 &&
@@ -1303,7 +1314,7 @@ int stem_pool_forward(const SplitConvParams& p, const void* staged_planar, int b
     a.w = static_cast<const uint8_t*>(p.w);
     a.bias = p.bias; a.post_scale = post_scale; a.post_shift = post_shift;
     a.Wpad = staged_planar_width(w);
-    a.y32 = y32; a.ysplit = static_cast<uint8_t*>(ysplit); a.w_inv_scale = p.w_inv_scale;
+    a.y32 = y32; a.ysplit = static_cast<uint8_t*>(ysplit); a.clamped = clamped; a.w_inv_scale = p.w_inv_scale;
     a.H = h; a.W = w; a.Ho = s.out_h(h); a.Wo = s.out_w(w);
     a.Hp = (a.Ho + 2 - 3) / 2 + 1; a.Wp = (a.Wo + 2 - 3) / 2 + 1;
     a.tiles_y = ceil_div(a.Hp, PH); a.tiles_x = ceil_div(a.Wp, PW);

@@ -19,6 +19,7 @@ struct SplitConvOut {
     const float* post_shift = nullptr;
     float* splitk_ws = nullptr;        // optional workspace for split-K partial sums (small grids only)
     size_t splitk_ws_floats = 0;
+    unsigned* clamped = nullptr;       // device counter of values that left the fp16 range while being split, or NULL
 };
 
 int pack_conv_weights_split(const float* w_oihw, int cin_w, const ConvShape& s, const float* out_scale, float wscale,
@@ -51,14 +52,15 @@ int unit_fused_forward(const SplitConvParams& conv1, const SplitConvParams& conv
 // convolution, all on the split input act) in one kernel writing the float32 sum; *taken as above.
 int unit_proj_fused_forward(const SplitConvParams& conv1, const SplitConvParams& conv2, const SplitConvParams& conv3,
                             const SplitConvParams& shortcut, const void* act_split, int batch, int h, int w, float* y32,
-                            hipStream_t stream, bool* taken);
+                            unsigned* clamped, hipStream_t stream, bool* taken);
 
 // float32 [rows][channels] -> split, optionally through relu(x * scale[c] + shift[c]).
+// (`clamped` in this and the following functions: the device counter described at SplitConvOut, may be NULL)
 int to_split(const float* x, long long rows, int channels, const float* scale, const float* shift, void* y,
-             hipStream_t stream);
+             unsigned* clamped, hipStream_t stream);
 
 int stage_input_split(const uint8_t* frames, int batch, int h, int w, const InputNorm& norm, void* y,
-                      hipStream_t stream);
+                      unsigned* clamped, hipStream_t stream);
 
 // The 7x7/2 stem (bn0+ReLU folded) and the 3x3/2 max-pool in one kernel: staged split image ->
 // pooled split activations with relu(x * post_scale + post_shift) applied (and float32 pooled
@@ -66,12 +68,12 @@ int stage_input_split(const uint8_t* frames, int batch, int h, int w, const Inpu
 // (input: the planar staged image written by stage_input_planar)
 int staged_planar_width(int w);
 int stage_input_planar(const uint8_t* frames, int batch, int h, int w, const InputNorm& norm, void* y,
-                       hipStream_t stream);
+                       unsigned* clamped, hipStream_t stream);
 int stem_pool_forward(const SplitConvParams& p, const void* staged_planar, int batch, int h, int w,
                       const float* post_scale, const float* post_shift, float* y32, void* ysplit,
-                      hipStream_t stream);
+                      unsigned* clamped, hipStream_t stream);
 
 int maxpool_3x3s2_split(const float* x, int batch, int h, int w, int c, const float* scale, const float* shift,
-                        float* y32, void* ysplit, hipStream_t stream);
+                        float* y32, void* ysplit, unsigned* clamped, hipStream_t stream);
 
 }  // namespace fd

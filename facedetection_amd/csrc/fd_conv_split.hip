@@ -76,7 +76,7 @@ __global__ __launch_bounds__(256, 2) void conv_split_kernel(SplitKArgs a) {
 
     f32x4 ra[RA], rb[RB];
     f32x4 psc = {1.f, 1.f, 1.f, 1.f}, psh = {0.f, 0.f, 0.f, 0.f};
-    unsigned okbits = 0;
+    unsigned okbits = 0, bad = 0;
     int kh = 0, kw = 0, coff = 0;
     const int nk = a.K / SBK;
 
@@ -121,7 +121,7 @@ __global__ __launch_bounds__(256, 2) void conv_split_kernel(SplitKArgs a) {
                     float t_ = fmaxf(v_[j] * psc[j] + psh[j], 0.f);                               \
                     if (!((okbits >> i) & 1u)) t_ = 0.f;                                          \
                     _Float16 hh_, ll_;                                                            \
-                    split_f32(t_, hh_, ll_);                                                      \
+                    split_f32(t_, hh_, ll_, bad);                                                 \
                     h_[j] = hh_; l_[j] = ll_;                                                     \
                 }                                                                                 \
                 *reinterpret_cast<f16x4*>(row_ + c4 * 2) = h_;                                    \
@@ -269,7 +269,7 @@ __global__ __launch_bounds__(256, 2) void conv_split_kernel(SplitKArgs a) {
                         }
                     }
                     f16x8 hi, lo;
-                    split8(v0, v1, hi, lo);
+                    split8(v0, v1, hi, lo, bad);
                     uint8_t* sp = a.ysplit + (size_t)row * a.Cout * 4 + split_offset(gcol);
                     *reinterpret_cast<f16x8*>(sp) = hi;
                     *reinterpret_cast<f16x8*>(sp + 64) = lo;
@@ -277,6 +277,7 @@ __global__ __launch_bounds__(256, 2) void conv_split_kernel(SplitKArgs a) {
             }
         }
     }
+    split_report(a.clamped, bad);
 }
 
 // ---------------------------------------------------------------------------------
@@ -566,7 +567,7 @@ __global__ __launch_bounds__(256, 2) void conv_split_reg_kernel(SplitKArgs a, un
         kh = tap / a.KW;
         kw = tap - kh * a.KW;
     }
-    unsigned avo[RA], okbits = 0;
+    unsigned avo[RA], okbits = 0, bad = 0;
     f32x4 ra[RA];
     f32x4 psc = {1.f, 1.f, 1.f, 1.f}, psh = {0.f, 0.f, 0.f, 0.f};
 
@@ -621,7 +622,7 @@ __global__ __launch_bounds__(256, 2) void conv_split_reg_kernel(SplitKArgs a, un
                     float t_ = ra[i][j] * psc[j] + psh[j];                                        \
                     if (!((lok >> i) & 1u)) t_ = 0.f;                                             \
                     _Float16 hh_, ll_;                                                            \
-                    split_f32_relu(t_, hh_, ll_);                                                 \
+                    split_f32_relu(t_, hh_, ll_, bad);                                            \
                     h_[j] = hh_; l_[j] = ll_;                                                     \
                 }                                                                                 \
             } else {                                                                              \
@@ -675,6 +676,7 @@ __global__ __launch_bounds__(256, 2) void conv_split_reg_kernel(SplitKArgs a, un
 #undef FD_LSTORE
 #undef FD_GLOAD
 #undef FD_TAP
+    if (MODE == REG_PRE) split_report(a.clamped, bad);
     if (a.ksplit > 1) {
         SplitKArgs e = a;
         e.y32 = a.partial + (size_t)ks * a.M * a.Cout;
@@ -764,7 +766,9 @@ __global__ __launch_bounds__(256) void split_k_finish_kernel(SplitKArgs a) {
             }
         }
         f16x8 hi, lo;
-        split8(v0, v1, hi, lo);
+        unsigned bad = 0;
+        split8(v0, v1, hi, lo, bad);
+        split_report(a.clamped, bad);
         uint8_t* sp = a.ysplit + (size_t)row * a.Cout * 4 + split_offset(col);
         *reinterpret_cast<f16x8*>(sp) = hi;
         *reinterpret_cast<f16x8*>(sp + 64) = lo;
@@ -817,7 +821,7 @@ static int split_conv_dispatch(const SplitConvParams& p, const void* x_split, co
     a.pre_scale = pre_scale; a.pre_shift = pre_shift;
     a.H = h; a.W = w; a.Cin = s.cin; a.Ho = ho; a.Wo = wo; a.Cout = s.cout; a.KW = s.kwp;
     a.stride = s.stride; a.pad = s.pad; a.K = s.k(); a.M = (int)m_ll; a.relu = p.relu; a.tiles_n = 0;
-    a.ksplit = 1; a.kchunk = a.K / SBK; a.partial = nullptr;
+    a.ksplit = 1; a.kchunk = a.K / SBK; a.partial = nullptr; a.clamped = out.clamped;
     FD_REQUIRE(!(stem && pre_scale), "split conv: the stem takes the staged image only");
     // the buffer-addressed kernels use 32-bit byte offsets below 2^31 into both tensors
     const size_t x_bytes = (size_t)batch * h * w * s.cin * 4, w_bytes = s.packed_floats() * 4;
@@ -902,7 +906,8 @@ __global__ __launch_bounds__(256) void pack_split_kernel(const float* __restrict
         v *= wscale;
     }
     _Float16 hi, lo;
-    split_f32(v, hi, lo);
+    unsigned bad = 0;                  // the host chose wscale so that every weight is in range
+    split_f32(v, hi, lo, bad);
     uint8_t* row = out + (size_t)o * K * 4 + (size_t)(k >> 5) * 128 + (size_t)(k & 31) * 2;
     *reinterpret_cast<_Float16*>(row) = hi;
     *reinterpret_cast<_Float16*>(row + 64) = lo;
@@ -922,7 +927,7 @@ int pack_conv_weights_split(const float* w_oihw, int cin_w, const ConvShape& s, 
 // float32 [rows][C] -> split [rows][C], optionally through relu(x * scale[c] + shift[c])
 __global__ __launch_bounds__(256) void to_split_kernel(const float* __restrict__ x, long long rows, int C,
                                                       const float* __restrict__ scale, const float* __restrict__ shift,
-                                                      uint8_t* __restrict__ y) {
+                                                      uint8_t* __restrict__ y, unsigned* __restrict__ clamped) {
     const long long t = (long long)blockIdx.x * 256 + threadIdx.x;     // one thread per 8 channels
     const int c8n = C / 8;
     if (t >= rows * c8n) return;
@@ -940,19 +945,21 @@ __global__ __launch_bounds__(256) void to_split_kernel(const float* __restrict__
         }
     }
     f16x8 hi, lo;
-    split8(v0, v1, hi, lo);
+    unsigned bad = 0;
+    split8(v0, v1, hi, lo, bad);
+    split_report(clamped, bad);
     uint8_t* sp = y + (size_t)r * C * 4 + split_offset(c);
     *reinterpret_cast<f16x8*>(sp) = hi;
     *reinterpret_cast<f16x8*>(sp + 64) = lo;
 }
 
 int to_split(const float* x, long long rows, int channels, const float* scale, const float* shift, void* y,
-             hipStream_t stream) {
+             unsigned* clamped, hipStream_t stream) {
     FD_REQUIRE(x && y && channels % 32 == 0, "to_split: channels must be a multiple of 32");
     if (rows <= 0) return FD_OK;
     ProfScope scope(stream, "to_split", 0.0, 8.0 * (double)rows * channels);
     hipLaunchKernelGGL(to_split_kernel, dim3(ceil_div(rows * (channels / 8), 256)), dim3(256), 0, stream, x, rows,
-                       channels, scale, shift, static_cast<uint8_t*>(y));
+                       channels, scale, shift, static_cast<uint8_t*>(y), clamped);
     FD_LAUNCH_CHECK();
     return FD_OK;
 }
@@ -960,30 +967,33 @@ int to_split(const float* x, long long rows, int channels, const float* scale, c
 // ---------------------------------------------------------------------------------
 // uint8 frames -> split staged image [B][H][W][4 hi | 4 lo] with bn_data applied
 __global__ __launch_bounds__(256) void stage_input_split_kernel(const uint8_t* __restrict__ f, long long pixels,
-                                                               InputNorm n, f16x8* __restrict__ y) {
+                                                               InputNorm n, f16x8* __restrict__ y,
+                                                               unsigned* __restrict__ clamped) {
     const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
     if (t >= pixels) return;
     const uint8_t* p = f + t * 3;
     f16x8 o;
+    unsigned bad = 0;
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
         _Float16 hi, lo;
-        split_f32((float)p[c] * n.scale[c] + n.shift[c], hi, lo);
+        split_f32((float)p[c] * n.scale[c] + n.shift[c], hi, lo, bad);
         o[c] = hi;
         o[4 + c] = lo;
     }
     o[3] = (_Float16)0.f;
     o[7] = (_Float16)0.f;
     y[t] = o;
+    split_report(clamped, bad);
 }
 
 int stage_input_split(const uint8_t* frames, int batch, int h, int w, const InputNorm& norm, void* y,
-                      hipStream_t stream) {
+                      unsigned* clamped, hipStream_t stream) {
     FD_REQUIRE(frames && y, "stage_input_split: NULL tensor");
     const long long pixels = (long long)batch * h * w;
     ProfScope scope(stream, "stage_input", 0.0, 19.0 * (double)pixels);
     hipLaunchKernelGGL(stage_input_split_kernel, dim3(ceil_div(pixels, 256)), dim3(256), 0, stream, frames, pixels, norm,
-                       static_cast<f16x8*>(y));
+                       static_cast<f16x8*>(y), clamped);
     FD_LAUNCH_CHECK();
     return FD_OK;
 }
@@ -996,36 +1006,38 @@ int staged_planar_width(int w) { return (w + 8 + 1) & ~1; }
 
 __global__ __launch_bounds__(256) void stage_input_planar_kernel(const uint8_t* __restrict__ f, int W, int Wpad,
                                                                 long long slots, InputNorm n, f16x4* __restrict__ hi,
-                                                                f16x4* __restrict__ lo) {
+                                                                f16x4* __restrict__ lo, unsigned* __restrict__ clamped) {
     const long long t = (long long)blockIdx.x * 256 + threadIdx.x;      // one slot (row, column) of a plane
     if (t >= slots) return;
     const int col = (int)(t % Wpad);
     const long long row = t / Wpad;                                      // image row over the whole batch
     f16x4 h = {(_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f}, l = h;
     const int x = col - 3;
+    unsigned bad = 0;
     if ((unsigned)x < (unsigned)W) {
         const uint8_t* p = f + (row * W + x) * 3;
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             _Float16 a, b;
-            split_f32((float)p[c] * n.scale[c] + n.shift[c], a, b);
+            split_f32((float)p[c] * n.scale[c] + n.shift[c], a, b, bad);
             h[c] = a;
             l[c] = b;
         }
     }
     hi[t] = h;
     lo[t] = l;
+    split_report(clamped, bad);
 }
 
 int stage_input_planar(const uint8_t* frames, int batch, int h, int w, const InputNorm& norm, void* y,
-                       hipStream_t stream) {
+                       unsigned* clamped, hipStream_t stream) {
     FD_REQUIRE(frames && y, "stage_input_planar: NULL tensor");
     const int wpad = staged_planar_width(w);
     const long long slots = (long long)batch * h * wpad;
     ProfScope scope(stream, "stage_input", 0.0, 3.0 * batch * h * (double)w + 16.0 * (double)slots);
     f16x4* hi = static_cast<f16x4*>(y);
     hipLaunchKernelGGL(stage_input_planar_kernel, dim3((unsigned)ceil_div(slots, 256)), dim3(256), 0, stream, frames, w,
-                       wpad, slots, norm, hi, hi + slots);
+                       wpad, slots, norm, hi, hi + slots, clamped);
     FD_LAUNCH_CHECK();
     return FD_OK;
 }
@@ -1036,7 +1048,7 @@ int stage_input_planar(const uint8_t* frames, int batch, int h, int w, const Inp
 __global__ __launch_bounds__(256) void maxpool_split_kernel(const float* __restrict__ x, int B, int H, int W, int C, int Ho,
                                                            int Wo, const float* __restrict__ scale,
                                                            const float* __restrict__ shift, float* __restrict__ y32,
-                                                           uint8_t* __restrict__ ysplit) {
+                                                           uint8_t* __restrict__ ysplit, unsigned* __restrict__ clamped) {
     const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
     const int c8n = C / 8;
     if (t >= (long long)B * Ho * Wo * c8n) return;
@@ -1075,7 +1087,9 @@ __global__ __launch_bounds__(256) void maxpool_split_kernel(const float* __restr
             }
         }
         f16x8 hi, lo;
-        split8(m0, m1, hi, lo);
+        unsigned bad = 0;
+        split8(m0, m1, hi, lo, bad);
+        split_report(clamped, bad);
         uint8_t* sp = ysplit + (size_t)pix * C * 4 + split_offset(c);
         *reinterpret_cast<f16x8*>(sp) = hi;
         *reinterpret_cast<f16x8*>(sp + 64) = lo;
@@ -1083,14 +1097,14 @@ __global__ __launch_bounds__(256) void maxpool_split_kernel(const float* __restr
 }
 
 int maxpool_3x3s2_split(const float* x, int batch, int h, int w, int c, const float* scale, const float* shift,
-                        float* y32, void* ysplit, hipStream_t stream) {
+                        float* y32, void* ysplit, unsigned* clamped, hipStream_t stream) {
     FD_REQUIRE(x && (y32 || ysplit) && c % 32 == 0, "maxpool (split): bad arguments");
     const int ho = (h + 2 - 3) / 2 + 1, wo = (w + 2 - 3) / 2 + 1;
     const long long total = (long long)batch * ho * wo * (c / 8);
     ProfScope scope(stream, "maxpool_3x3s2", 0.0,
                     4.0 * c * ((double)batch * h * w + (double)batch * ho * wo * ((y32 ? 1 : 0) + (ysplit ? 1 : 0))));
     hipLaunchKernelGGL(maxpool_split_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, stream, x, batch, h, w, c, ho, wo,
-                       scale, shift, y32, static_cast<uint8_t*>(ysplit));
+                       scale, shift, y32, static_cast<uint8_t*>(ysplit), clamped);
     FD_LAUNCH_CHECK();
     return FD_OK;
 }
@@ -1131,7 +1145,7 @@ int fd_conv2d_f16x3(fd_ctx* ctx, const float* x_nhwc, int batch, int height, int
     // with a BatchNorm+ReLU prologue the kernel converts float32 input while staging it
     if (pre_scale && pre_shift)
         return fd::split_conv_forward_f32(p, x_nhwc, pre_scale, pre_shift, batch, height, width, residual, o, st);
-    FD_TRY(fd::to_split(x_nhwc, (long long)batch * height * width, cin, nullptr, nullptr, xs, st));
+    FD_TRY(fd::to_split(x_nhwc, (long long)batch * height * width, cin, nullptr, nullptr, xs, nullptr, st));
     return fd::split_conv_forward(p, xs, batch, height, width, residual, o, st);
 }
 

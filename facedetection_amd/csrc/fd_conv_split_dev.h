@@ -25,6 +25,7 @@ struct SplitKArgs {
     // writes its scaled partial sums to partial[ks][M][Cout]; split_k_finish_kernel adds them up
     int ksplit, kchunk;
     float* partial;
+    unsigned* clamped;       // device counter of values outside the fp16 range met while splitting (may be NULL)
 };
 
 constexpr int SBK = 32;      // k per K-step
@@ -165,6 +166,7 @@ __device__ __forceinline__ void split_epilogue16_rows(const SplitKArgs& a, float
 #pragma unroll
     for (int mi = 0; mi < BM / 64; ++mi) {
         const int lrow0 = wm * (BM / 2) + mi * 32;
+        unsigned bad = 0;      // per row group: keeps the count out of the registers live across groups
         f32x4 res0[PASSES], res1[PASSES];
         if (PREFETCHED) {
 #pragma unroll
@@ -227,13 +229,14 @@ __device__ __forceinline__ void split_epilogue16_rows(const SplitKArgs& a, float
                         }
                     }
                     f16x8 hi, lo;
-                    split8(v0, v1, hi, lo);
+                    split8(v0, v1, hi, lo, bad);
                     uint8_t* sp = a.ysplit + (size_t)row * a.Cout * 4 + split_offset(gcol);
                     *reinterpret_cast<f16x8*>(sp) = hi;
                     *reinterpret_cast<f16x8*>(sp + 64) = lo;
                 }
             }
         }
+        if (a.ysplit) split_report(a.clamped, bad);
     }
 }
 

@@ -52,7 +52,8 @@ struct fd_detector {
     int precision = FD_PRECISION_F16X3;
     const float *bn1_scale = nullptr, *bn1_shift = nullptr;
     const float *w_cls = nullptr, *b_cls = nullptr, *w_box = nullptr, *b_box = nullptr;
-    int32_t* nan_flag = nullptr;
+    int32_t* nan_flag = nullptr;         // status block on the device: [0] NaN met by the proposal stage,
+    unsigned* clamped = nullptr;         // [1] values outside the fp16 range met while splitting (this pass)
     std::vector<fd::Tap> taps;
     fd::Buf net[fd::NB_COUNT];
     bool keep_taps = false;              // debugging: snapshot every tapped tensor
@@ -79,6 +80,14 @@ struct ParamTable {
                       (long long)numel);
             return nullptr;
         }
+        // A NaN or Inf weight would make every score NaN (the reference then raises ValueError in its
+        // proposal stage on every frame); the split format cannot even carry it.  Refuse it here.
+        const float* v = it->second->data_host;
+        for (int64_t i = 0; i < numel; ++i)
+            if (!std::isfinite(v[i])) {
+                set_error("parameter '%s' holds a non-finite value at element %lld", name.c_str(), (long long)i);
+                return nullptr;
+            }
         return it->second;
     }
 };
@@ -261,6 +270,7 @@ static int build(fd_detector* d, const ParamTable& t) {
     FD_HIP(hipMemset(flag, 0, 256));
     d->owned.push_back(flag);
     d->nan_flag = static_cast<int32_t*>(flag);
+    d->clamped = reinterpret_cast<unsigned*>(d->nan_flag + 1);
     return FD_OK;
 }
 
@@ -284,6 +294,7 @@ struct Plan {
         SplitConvOut o;
         o.splitk_ws = buf(NB_SPLITK, SPLITK_FLOATS);
         o.splitk_ws_floats = SPLITK_FLOATS;
+        o.clamped = d->clamped;
         return o;
     }
     void tap(const char* name, const float* p, int64_t a, int64_t b, int64_t c, int64_t e) {
@@ -334,7 +345,10 @@ static int run_graph(Plan& pl, const uint8_t* frames, int B, int H, int W, float
     fd_detector* d = pl.d;
     const int R = d->prop.post_nms_top_n;
     float* staged = pl.buf(NB_STAGED, (size_t)B * H * W * 4);
-    if (!pl.dry) FD_TRY(stage_input(frames, B, H, W, d->norm, staged, pl.stream));
+    if (!pl.dry) {
+        FD_HIP(hipMemsetAsync(d->clamped, 0, sizeof(unsigned), pl.stream));     // float32 operands: nothing is clamped
+        FD_TRY(stage_input(frames, B, H, W, d->norm, staged, pl.stream));
+    }
     const int h1 = d->conv0.s.out_h(H), w1 = d->conv0.s.out_w(W);
     float* c0 = pl.buf(NB_CONV0, (size_t)B * h1 * w1 * FILTERS[0]);
     if (!pl.dry) FD_TRY(conv_forward(d->conv0, staged, B, H, W, nullptr, c0, pl.stream));
@@ -443,8 +457,8 @@ static int run_unit_split(Plan& pl, const Unit& u, const char* name, const void*
     // accumulated together, so neither the shortcut tensor nor t1/t2 exist
     bool whole_proj = false;
     if (u.has_sc && !pl.dry && (!pl.d->keep_taps || (pl.d->fuse_units & 4)) && (pl.d->fuse_units & 2) && y32 && !ysplit)
-        FD_TRY(unit_proj_fused_forward(u.s_conv1, u.s_conv2, u.s_conv3, u.s_sc, act, n, h, w, y32, pl.stream,
-                                       &whole_proj));
+        FD_TRY(unit_proj_fused_forward(u.s_conv1, u.s_conv2, u.s_conv3, u.s_sc, act, n, h, w, y32, pl.d->clamped,
+                                       pl.stream, &whole_proj));
     if (u.has_sc) {
         float* s = pl.buf(NB_SC, (size_t)n * ho * wo * cout);
         if (!pl.dry && !whole_proj) {
@@ -504,8 +518,9 @@ static int run_graph_split(Plan& pl, const uint8_t* frames, int B, int H, int W,
     const bool fused_stem = !keep && planar_floats * 4 < (1ull << 31);
     float* staged = pl.buf(NB_STAGED, fused_stem ? planar_floats : (size_t)B * H * W * 4);
     if (!pl.dry) {
-        if (fused_stem) FD_TRY(stage_input_planar(frames, B, H, W, d->norm, staged, pl.stream));
-        else FD_TRY(stage_input_split(frames, B, H, W, d->norm, staged, pl.stream));
+        FD_HIP(hipMemsetAsync(d->clamped, 0, sizeof(unsigned), pl.stream));
+        if (fused_stem) FD_TRY(stage_input_planar(frames, B, H, W, d->norm, staged, d->clamped, pl.stream));
+        else FD_TRY(stage_input_split(frames, B, H, W, d->norm, staged, d->clamped, pl.stream));
     }
     float* c0 = fused_stem ? nullptr : pl.buf(NB_CONV0, (size_t)B * h1 * w1 * FILTERS[0]);
     if (!pl.dry && !fused_stem) {
@@ -530,10 +545,11 @@ static int run_graph_split(Plan& pl, const uint8_t* frames, int B, int H, int W,
     if (!pl.dry) {
         if (fused_stem)
             FD_TRY(stem_pool_forward(d->s_conv0, staged, B, H, W, d->stage[0][0].bn1_scale, d->stage[0][0].bn1_shift,
-                                     nullptr, abuf[0], pl.stream));
+                                     nullptr, abuf[0], d->clamped, pl.stream));
         else
             FD_TRY(maxpool_3x3s2_split(c0, B, h1, w1, FILTERS[0], d->stage[0][0].bn1_scale,
-                                       d->stage[0][0].bn1_shift, keep ? xbuf[0] : nullptr, abuf[0], pl.stream));
+                                       d->stage[0][0].bn1_shift, keep ? xbuf[0] : nullptr, abuf[0], d->clamped,
+                                       pl.stream));
     }
     if (keep) pl.tap("pool0", xbuf[0], B, h, w, FILTERS[0]);
     int cur = 0;
@@ -597,10 +613,11 @@ static int run_graph_split(Plan& pl, const uint8_t* frames, int B, int H, int W,
         if (keep) {
             FD_TRY(roipool_nhwc(feat, B, FILTERS[3], fh, fw, rois, N, POOLED, POOLED, 1.0f / 16.0f, pooled, pl.stream));
             FD_TRY(to_split(pooled, (long long)N * POOLED * POOLED, FILTERS[3], d->stage[3][0].bn1_scale,
-                            d->stage[3][0].bn1_shift, a4buf[0], pl.stream));
+                            d->stage[3][0].bn1_shift, a4buf[0], d->clamped, pl.stream));
         } else {
             FD_TRY(roipool_nhwc_split(feat, B, FILTERS[3], fh, fw, rois, N, POOLED, POOLED, 1.0f / 16.0f,
-                                      d->stage[3][0].bn1_scale, d->stage[3][0].bn1_shift, a4buf[0], pl.stream));
+                                      d->stage[3][0].bn1_scale, d->stage[3][0].bn1_shift, a4buf[0], d->clamped,
+                                      pl.stream));
         }
     }
     if (keep) pl.tap("pooled", pooled, N, POOLED, POOLED, FILTERS[3]);
@@ -783,6 +800,12 @@ int fd_detect_scaled(fd_detector* d, const uint8_t* frames, int batch, int heigh
         FD_LAUNCH_CHECK();
     }
     if (nan_flag) FD_HIP(hipMemcpyAsync(nan_flag, d->nan_flag, sizeof(int32_t), hipMemcpyDeviceToDevice, s));
+    return FD_OK;
+}
+
+int fd_detector_status(fd_detector* d, int32_t* status, void* stream) {
+    FD_REQUIRE(d && status, "fd_detector_status: NULL argument");
+    FD_HIP(hipMemcpyAsync(status, d->nan_flag, 2 * sizeof(int32_t), hipMemcpyDeviceToDevice, fd::as_stream(stream)));
     return FD_OK;
 }
 

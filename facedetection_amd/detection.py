@@ -51,10 +51,21 @@ def load_model(model_path, epoch=0):
 class Detector:
     """Faster R-CNN face detector (ResNet-50 backbone) on one MI355X."""
 
-    def __init__(self, model_path, ctx=None, epoch=0, box_f64=True, precision="f16x3", own_context=False):
+    def __init__(self, model_path, ctx=None, epoch=0, box_f64=True, precision="f16x3", own_context=False,
+                 on_clamp="fallback"):
         """``own_context``: give this detector a library context (scratch memory) of its own
         instead of the per-GPU shared one, so that it can run concurrently with other
-        detectors of the process on a different HIP stream."""
+        detectors of the process on a different HIP stream.
+
+        ``on_clamp``: what the host-side calls (``detect_face``, ``detect_batch``, ...) do when a
+        pass in "f16x3" precision had to clamp a value to the fp16 range, i.e. left the range in
+        which that arithmetic is as good as the reference's float32: "fallback" (default) repeats
+        the batch in "f32" precision, "raise" raises OverflowError, "ignore" returns the clamped
+        result.  ``clamp_fallbacks`` counts the repeated batches."""
+        if on_clamp not in ("fallback", "raise", "ignore"):
+            raise ValueError("on_clamp must be 'fallback', 'raise' or 'ignore'")
+        self.on_clamp = on_clamp
+        self.clamp_fallbacks = 0
         config.TEST.RPN_MIN_SIZE = 50            # detection.py:27
         self.device = _device_of(ctx)
         self.ctx = ctx
@@ -151,29 +162,65 @@ class Detector:
             box = runtime.empty((B * R, 8), torch.float32, self.device)
             _lib.check(self._lib.fd_forward(self._h, runtime.ptr(f), B, H, W, float(im_scale), runtime.ptr(rois),
                                             runtime.ptr(cls), runtime.ptr(box), runtime.stream_ptr(self.device)))
+            if self._check_status(self.status_device()):
+                return self._in_f32(lambda: self.forward(f, im_scale))
             return rois.cpu().numpy(), cls.cpu().numpy(), box.cpu().numpy()
+
+    def status_device(self):
+        """Status block of the last pass as a device int32 [2] tensor: (NaN flag, clamped values)."""
+        status = runtime.empty((2,), torch.int32, self.device)
+        _lib.check(self._lib.fd_detector_status(self._h, runtime.ptr(status), runtime.stream_ptr(self.device)))
+        return status
+
+    def clamped_values(self):
+        """Values the last pass had to clamp to the fp16 range (host read; 0 in "f32" precision)."""
+        with torch.cuda.device(self.device):
+            return int(self.status_device()[1].item())
 
     def detect_batch_device(self, frames, nms_thresh=0.3, thresh=0.8, do_round=True):
         """Asynchronous batched detection: frames uint8 [B,H,W,3] already on the GPU.
-        Returns device tensors (dets [B,R,5], n_dets [B], nan_flag [1]); no host sync."""
+        Returns device tensors (dets [B,R,5], n_dets [B], status [2] = (NaN flag, clamped values));
+        no host sync, and therefore no float32 fallback: the caller inspects ``status``."""
         B, H, W, _ = frames.shape
         R = self.rois_per_image
         dets = runtime.empty((B, R, 5), torch.float32, self.device)
         n = runtime.empty((B,), torch.int32, self.device)
-        flag = runtime.empty((1,), torch.int32, self.device)
+        status = runtime.empty((2,), torch.int32, self.device)
+        stream = runtime.stream_ptr(self.device)
         _lib.check(self._lib.fd_detect(self._h, runtime.ptr(frames), B, H, W, float(thresh), float(nms_thresh),
-                                       1 if do_round else 0, runtime.ptr(dets), runtime.ptr(n), runtime.ptr(flag),
-                                       runtime.stream_ptr(self.device)))
-        return dets, n, flag
+                                       1 if do_round else 0, runtime.ptr(dets), runtime.ptr(n), None, stream))
+        _lib.check(self._lib.fd_detector_status(self._h, runtime.ptr(status), stream))
+        return dets, n, status
+
+    def _check_status(self, status):
+        """Host read of a pass's status block: raises like the reference on NaN; returns True when the
+        caller has to repeat the pass in float32 (values were clamped and ``on_clamp`` says so)."""
+        nan, clamped = (int(v) for v in status.cpu().numpy())
+        if nan != 0:
+            raise ValueError("there is nan in input scores or bbox_deltas")
+        if clamped != 0 and self.precision == "f16x3":
+            if self.on_clamp == "raise":
+                raise OverflowError("%d values left the fp16 range of the f16x3 arithmetic" % clamped)
+            return self.on_clamp == "fallback"
+        return False
+
+    def _in_f32(self, fn):
+        """Runs fn() with the detector switched to float32 operands, then switches back."""
+        self.clamp_fallbacks += 1
+        self.set_precision("f32")
+        try:
+            return fn()
+        finally:
+            self.set_precision("f16x3")
 
     def detect_batch(self, frames, nms_thresh=0.3, thresh=0.8, do_round=True):
         """List of float32 [n_i,5] arrays, one per frame of a same-size batch."""
         with torch.cuda.device(self.device):
             f = self._frames(frames)
-            dets, n, flag = self.detect_batch_device(f, nms_thresh, thresh, do_round)
+            dets, n, status = self.detect_batch_device(f, nms_thresh, thresh, do_round)
+            if self._check_status(status):
+                return self._in_f32(lambda: self.detect_batch(f, nms_thresh, thresh, do_round))
             n_host = n.cpu().numpy()
-            if int(flag.item()) != 0:
-                raise ValueError("there is nan in input scores or bbox_deltas")
             dets_host = dets.cpu().numpy()
             return [dets_host[b, :n_host[b]].copy() for b in range(f.shape[0])]
 
@@ -200,13 +247,14 @@ class Detector:
             dets = runtime.empty((B, R, 5), torch.float32, self.device)
             n = runtime.empty((B,), torch.int32, self.device)
             src = runtime.empty((B, R, 4), torch.int32, self.device)
-            flag = runtime.empty((1,), torch.int32, self.device)
+            status = runtime.empty((2,), torch.int32, self.device)
             _lib.check(self._lib.fd_detect_scaled(self._h, runtime.ptr(small), B, dh.value, dw.value, scale,
                                                   float(thresh), float(nms_thresh), runtime.ptr(dets), runtime.ptr(n),
-                                                  runtime.ptr(src), runtime.ptr(flag), stream))
+                                                  runtime.ptr(src), None, stream))
+            _lib.check(self._lib.fd_detector_status(self._h, runtime.ptr(status), stream))
+            if self._check_status(status):
+                return self._in_f32(lambda: self.detect_scaled_batch(f, target_size, max_size, nms_thresh, thresh, bgr))
             n_host = n.cpu().numpy()
-            if int(flag.item()) != 0:
-                raise ValueError("there is nan in input scores or bbox_deltas")
             d_host, s_host = dets.cpu().numpy(), src.cpu().numpy()
             return ([d_host[b, :n_host[b]].copy() for b in range(B)],
                     [s_host[b, :n_host[b]].copy() for b in range(B)], scale)

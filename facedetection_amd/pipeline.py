@@ -34,7 +34,8 @@ class FramePipeline:
 
     def detect_device(self, frames, micro_batch=8, nms_thresh=0.3, thresh=0.8, do_round=True):
         """frames uint8 [N,H,W,3] on the GPU -> list, in frame order, of
-        (dets [b,R,5], n_dets [b], nan_flag [1]) device tensors per micro-batch.  Asynchronous:
+        (dets [b,R,5], n_dets [b], status [2] = (NaN flag, clamped values)) device tensors per
+        micro-batch.  Asynchronous:
         the caller's current stream waits for all side streams before this returns, so work
         queued on it afterwards (or a synchronize) sees the results."""
         outs = []
@@ -61,9 +62,12 @@ class FramePipeline:
         f = self.detectors[0]._frames(frames)
         outs = self.detect_device(f, micro_batch, nms_thresh, thresh, True)
         res = []
-        for dets, n, flag in outs:
-            if int(flag.item()) != 0:
-                raise ValueError("there is nan in input scores or bbox_deltas")
+        for j, (dets, n, status) in enumerate(outs):
+            det = self.detectors[j % len(self.detectors)]
+            if det._check_status(status):
+                # values left the fp16 range: this micro-batch again with float32 operands
+                res += det.detect_batch(f[j * micro_batch:(j + 1) * micro_batch], nms_thresh, thresh, True)
+                continue
             d, c = dets.cpu().numpy(), n.cpu().numpy()
             res += [d[b, :c[b]].copy() for b in range(d.shape[0])]
         return res

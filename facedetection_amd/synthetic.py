@@ -173,6 +173,31 @@ def synthetic_params(seed=0, calib=None):
     return p
 
 
+def scaled_params(params, s, eps=2e-5):
+    """The same network with every intermediate activation multiplied by ``s`` (a power of two):
+    in exact arithmetic the graph outputs do not change, so a float64 evaluation of the returned
+    parameters is a yardstick for how an arithmetic copes with large (s >> 1) or tiny (s << 1)
+    activations.  bn0 and the three BatchNorms of every unit get gamma, beta and moving_mean
+    multiplied by s and their variance replaced by (var + eps) s^2 - eps (the normalised value is
+    unchanged, the output is s times larger); convolutions are linear, the residual stream follows.
+    The two consumers that must see unscaled values undo it: the RPN's 3x3 weights are divided by
+    s, and the final bn1 keeps its gamma and beta."""
+    s = float(s)
+    q = {k: np.array(v, copy=True) for k, v in params.items()}
+    q["bn0_gamma"] = (q["bn0_gamma"] * s).astype(np.float32)
+    q["bn0_beta"] = (q["bn0_beta"] * s).astype(np.float32)
+    for name, _ in bn_shapes():
+        if name in ("bn_data", "bn0"):
+            continue
+        q[name + "_moving_mean"] = (q[name + "_moving_mean"] * s).astype(np.float32)
+        q[name + "_moving_var"] = ((q[name + "_moving_var"].astype(np.float64) + eps) * s * s - eps).astype(np.float32)
+        if name != "bn1":
+            q[name + "_gamma"] = (q[name + "_gamma"] * s).astype(np.float32)
+            q[name + "_beta"] = (q[name + "_beta"] * s).astype(np.float32)
+    q["rpn_conv_3x3_weight"] = (q["rpn_conv_3x3_weight"] / s).astype(np.float32)
+    return q
+
+
 def synthetic_image(height, width, seed=0, faces=3):
     """uint8 [H,W,3] frame: smooth low-frequency noise plus a few bright face-like blobs."""
     g = np.random.default_rng([int(seed), 0xFACE])

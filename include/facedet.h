@@ -205,7 +205,8 @@ void fd_detector_destroy(fd_detector* det);
  *                      (hi + lo, ~22 significant bits) and each product is formed as
  *                      hi*hi + hi*lo + lo*hi on the f16 matrix cores: float32-grade results
  *                      (same error level against a float64 reference) at 16/3 of the rate.
- *                      Activations are clamped to the fp16 range (+-65504).  Default. */
+ *                      Activations are clamped to the fp16 range (+-65504); every clamped value
+ *                      is counted (fd_detector_status).  Default. */
 #define FD_PRECISION_F32 0
 #define FD_PRECISION_F16X3 1
 int fd_detector_set_precision(fd_detector* det, int precision);
@@ -244,6 +245,20 @@ int fd_detect(fd_detector* det, const uint8_t* frames, int batch, int height, in
 int fd_detect_scaled(fd_detector* det, const uint8_t* frames, int batch, int height, int width, float im_scale,
                      float thresh, float nms_thresh, float* dets, int32_t* n_dets, int32_t* boxes_src,
                      int32_t* nan_flag, void* stream);
+
+/* Status of the LAST forward pass of this detector, copied to status [2] (device int32) on `stream`
+ * (the stream the pass was issued on):
+ *   status[0]  non-zero if the proposal stage met a NaN in its scores or deltas -- where the reference
+ *              raises ValueError (symbol/proposal.py:47-51);
+ *   status[1]  number of values that lay outside the fp16 range (|v| > 65504, Inf, NaN) when an
+ *              operand was split for FD_PRECISION_F16X3 and were clamped (saturating at 2^31 - 1 is
+ *              not attempted: a count that large wraps).  Always 0 for FD_PRECISION_F32.  A non-zero
+ *              count means the pass did not have float32-grade accuracy: repeat it with
+ *              FD_PRECISION_F32 (the Python Detector does).  The reference has no counterpart: it
+ *              computes in unbounded float32 throughout.
+ * Parameters themselves are checked when the detector is created: a NaN or Inf in any tensor makes
+ * fd_detector_create fail with FD_ERR_PARAM. */
+int fd_detector_status(fd_detector* det, int32_t* status, void* stream);
 
 int fd_detector_keep_tensors(fd_detector* det, int keep);
 int fd_detector_tensor(fd_detector* det, const char* name, float* out, int64_t capacity, int64_t* dims4,

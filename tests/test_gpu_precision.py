@@ -1,0 +1,135 @@
+"""The range of the f16x3 arithmetic (every float32 operand as an fp16 hi + lo pair): the same
+network with all activations scaled by 2^8 and by 2^-10 (synthetic.scaled_params: identical graph
+outputs in exact arithmetic), the clamp counter, the float32 fallback, and the parameter check.
+Yardstick: the float64 oracle on the same scaled parameters."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import network as onet
+
+pytestmark = pytest.mark.gpu
+
+PROP = dict(pre_nms_top_n=1000, post_nms_top_n=10, nms_thresh=0.7, min_size=50)
+H, W = 270, 480
+
+
+@pytest.fixture(scope="module")
+def base():
+    from facedetection_amd.synthetic import synthetic_image, synthetic_params
+    return synthetic_params(0), synthetic_image(H, W, seed=11)
+
+
+def run(params, img, precision, on_clamp="ignore"):
+    from facedetection_amd.detection import Detector
+    det = Detector(params, 0, precision=precision, on_clamp=on_clamp)
+    try:
+        rois, cls_prob, deltas = det.forward(img)
+        return dict(rois=rois, cls=cls_prob, box=deltas, clamped=det.clamped_values(), fallbacks=det.clamp_fallbacks,
+                    feat=det.tensor("feat"))
+    finally:
+        det.close()
+
+
+@pytest.fixture(scope="module", params=[0, 8, -10], ids=["x1", "x2^8", "x2^-10"])
+def scaled(base, request):
+    from facedetection_amd.synthetic import scaled_params
+    params, img = base
+    s = 2.0 ** request.param
+    q = scaled_params(params, s) if request.param else params
+    with torch.no_grad():
+        rois, cls_prob, deltas, _ = onet.forward(img, q, PROP, torch.float64)
+    return dict(s=s, params=q, img=img, ref=dict(rois=rois, cls=cls_prob, box=deltas),
+                f32=run(q, img, "f32"), split=run(q, img, "f16x3"))
+
+
+def test_scaling_leaves_the_float64_outputs_unchanged(base, scaled):
+    """Sanity of the construction: the oracle's outputs on the scaled network equal those on the
+    unscaled one (up to float32 rounding of the rescaled parameters)."""
+    params, img = base
+    with torch.no_grad():
+        _, cls0, box0, _ = onet.forward(img, params, PROP, torch.float64)
+    assert np.abs(scaled["ref"]["cls"] - cls0).max() < 2e-5
+    assert np.abs(scaled["ref"]["box"] - box0).max() < 2e-5
+
+
+def test_float32_operands_hold_the_bar_at_every_scale(scaled):
+    got, ref = scaled["f32"], scaled["ref"]
+    assert got["clamped"] == 0
+    assert np.abs(got["rois"] - ref["rois"]).max() <= 0.05
+    assert np.abs(got["cls"] - ref["cls"]).max() <= 1e-4           # the 1e-4 score bar
+    assert np.abs(got["box"] - ref["box"]).max() <= 1e-4
+    # the residual stream really is scaled: a few units at scale 1
+    assert 0.5 * scaled["s"] < np.abs(got["feat"]).max() < 500.0 * scaled["s"]
+
+
+def test_f16x3_against_float32_and_float64(scaled):
+    """Large activations (2^8): in range, same bar as float32.  Tiny activations (2^-10): the lo
+    halves fall into the fp16 subnormals (absolute floor 2^-25 per value, i.e. ~2^-15 relative to
+    values of 2^-10), so the margin shrinks: measured 6e-5 on the scores against 1e-6 at scale 1;
+    the bound asserted for this scale is 2e-4.  Real BatchNorm-normalised networks keep
+    activations at O(1)."""
+    got, f32, ref = scaled["split"], scaled["f32"], scaled["ref"]
+    assert got["clamped"] == 0, "no value of this network reaches 65504 at scale %g" % scaled["s"]
+    score_err = np.abs(got["cls"] - ref["cls"]).max()
+    box_err = np.abs(got["box"] - ref["box"]).max()
+    vs_f32 = np.abs(got["cls"] - f32["cls"]).max()
+    print("scale %g: f16x3 score error vs float64 %.3g, deltas %.3g, vs float32 %.3g" % (scaled["s"], score_err, box_err, vs_f32))
+    if scaled["s"] >= 1.0:
+        assert np.abs(got["rois"] - ref["rois"]).max() <= 0.05
+        assert score_err <= 1e-4 and box_err <= 1e-4 and vs_f32 <= 1e-4
+    else:
+        assert score_err <= 2e-4 and box_err <= 2e-4
+
+
+def test_values_beyond_the_fp16_range_are_counted_and_fall_back_to_float32(base):
+    """Scale 2^14 pushes the residual stream past 65504: the f16x3 pass reports clamped values, the
+    default detector repeats the pass with float32 operands (bit-identical to a float32 detector),
+    and on_clamp='raise' raises."""
+    from facedetection_amd.synthetic import scaled_params
+    params, img = base
+    q = scaled_params(params, 2.0 ** 14)
+    f32 = run(q, img, "f32")
+    assert f32["clamped"] == 0 and np.abs(f32["feat"]).max() > 65504.0
+    ignored = run(q, img, "f16x3", "ignore")
+    assert ignored["clamped"] > 0 and ignored["fallbacks"] == 0
+    fell_back = run(q, img, "f16x3", "fallback")
+    assert fell_back["fallbacks"] == 1
+    for k in ("rois", "cls", "box"):
+        np.testing.assert_array_equal(fell_back[k], f32[k])
+    with torch.no_grad():
+        _, cls_ref, _, _ = onet.forward(img, q, PROP, torch.float64)
+    assert np.abs(fell_back["cls"] - cls_ref).max() <= 1e-4
+    with pytest.raises(OverflowError):
+        run(q, img, "f16x3", "raise")
+
+
+def test_detect_face_falls_back_too(base):
+    from facedetection_amd.detection import Detector
+    from facedetection_amd.synthetic import scaled_params
+    params, img = base
+    q = scaled_params(params, 2.0 ** 14)
+    a = Detector(q, 0, precision="f16x3")
+    b = Detector(q, 0, precision="f32")
+    try:
+        da, db = a.detect_face(img, thresh=0.05), b.detect_face(img, thresh=0.05)
+        assert a.clamp_fallbacks == 1 and a.precision == "f16x3"
+        np.testing.assert_array_equal(da, db)
+        assert db.shape[0] > 0
+    finally:
+        a.close()
+        b.close()
+
+
+@pytest.mark.parametrize("bad", [np.nan, np.inf])
+def test_non_finite_parameters_are_refused_at_creation(base, bad):
+    from facedetection_amd import _lib
+    from facedetection_amd.detection import Detector
+    params, _ = base
+    q = dict(params)
+    w = q["stage2_unit3_conv2_weight"].copy()
+    w[5, 7, 1, 2] = bad
+    q["stage2_unit3_conv2_weight"] = w
+    with pytest.raises(_lib.FaceDetError) as e:
+        Detector(q, 0)
+    assert e.value.code == -5 and "stage2_unit3_conv2_weight" in str(e.value)

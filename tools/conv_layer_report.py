@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Per-layer convolution timing from a rocprofv3 kernel trace of bench.py.
 
-    python tools/conv_layer_report.py <kernel_trace.csv> [micro_batch]
+    python tools/conv_layer_report.py <kernel_trace.csv> [micro_batch] [f32]
 
 Takes the convolution launches of the last complete forward pass in the trace, pairs them with
 the layer list of faster_rcnn50 at 1080p (same order as the library issues them; the stem runs
@@ -11,7 +11,7 @@ import csv
 import sys
 
 
-def layer_list(B, H=1080, W=1920, R=10):
+def layer_list(B, H=1080, W=1920, R=10, fused=True):
     layers = []
 
     def conv(name, n, h, w, cin, cout, k, s, p):
@@ -19,6 +19,7 @@ def layer_list(B, H=1080, W=1920, R=10):
         layers.append((name, n * ho * wo, cout, cin * k * k, 2.0 * n * ho * wo * cout * cin * k * k))
         return ho, wo
 
+    # (a trailing "f32" argument describes the float32 path, which launches every layer on its own)
     h, w = conv("conv0", B, H, W, 3, 64, 7, 2, 3)
     h, w = (h + 2 - 3) // 2 + 1, (w + 2 - 3) // 2 + 1
     F, U = [64, 256, 512, 1024, 2048], [3, 4, 6, 3]
@@ -39,7 +40,7 @@ def layer_list(B, H=1080, W=1920, R=10):
             conv(nm + "_c1", n, h, w, cin, mid, 1, 1, 0)
             h2, w2 = conv(nm + "_c2", n, h, w, mid, mid, 3, st, 1)
             conv(nm + "_c3", n, h2, w2, mid, cout, 1, 1, 0)
-            if mid == 64 and st == 1:
+            if fused and mid == 64 and st == 1:
                 # the units of the 64-channel stage run as one fused kernel each
                 k = 4 if u == 0 else 3
                 parts = [layers.pop() for _ in range(k)]
@@ -53,7 +54,7 @@ def main():
     B = int(sys.argv[2]) if len(sys.argv) > 2 else 8
     rows = [r for r in csv.DictReader(open(path))
             if any(t in r["Kernel_Name"] for t in ("conv_igemm", "conv_split_", "stem_pool", "conv_tail_fused", "unit_fused", "unit_proj_fused"))]
-    layers = layer_list(B)
+    layers = layer_list(B, fused=not (len(sys.argv) > 3 and sys.argv[3] == "f32"))
     last = rows[-len(layers):]
     tot = totf = 0.0
     groups = {}
