@@ -5,6 +5,7 @@
 
 hipcc cross-compiles without a GPU; the resulting .so travels to the GPU box.
 """
+import hashlib
 import os
 import subprocess
 import sys
@@ -27,6 +28,19 @@ SOURCES = [
 COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 
 
+def source_id():
+    """sha256 (first 16 hex digits) over the library's sources: csrc/*.hip, csrc/*.h and
+    include/facedet.h, in name order.  Compiled into the library (fd_build_id) so that a
+    measurement file can name the kernel set it was taken on."""
+    files = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h")))
+    files.append(os.path.join(os.path.dirname(PKG), "include", "facedet.h"))
+    h = hashlib.sha256()
+    for f in files:
+        h.update(os.path.basename(f).encode() + b"\0")
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
 def _newer(a, b):
     return (not os.path.exists(b)) or os.path.getmtime(a) > os.path.getmtime(b)
 
@@ -37,13 +51,21 @@ def build(force=False, verbose=True):
     headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
     headers.append(os.path.join(os.path.dirname(PKG), "include", "facedet.h"))
     objs, rebuilt = [], False
+    # the id of this source set, as a generated header that only fd_core.hip includes
+    bid = source_id()
+    id_header = os.path.join(OBJ, "fd_build_id.h")
+    id_text = '#define FD_BUILD_ID "%s"\n' % bid
+    if not os.path.exists(id_header) or open(id_header).read() != id_text:
+        with open(id_header, "w") as f:
+            f.write(id_text)
     for src, extra in SOURCES:
         s = os.path.join(CSRC, src)
         if not os.path.exists(s):
             continue
         o = os.path.join(OBJ, src.replace(".hip", ".o"))
-        if force or _newer(s, o) or any(_newer(h, o) for h in headers):
-            cmd = [hipcc] + COMMON + extra + ["-c", s, "-o", o]
+        stale_id = src == "fd_core.hip" and _newer(id_header, o)
+        if force or stale_id or _newer(s, o) or any(_newer(h, o) for h in headers):
+            cmd = [hipcc] + COMMON + extra + ["-I", OBJ, "-c", s, "-o", o]
             if verbose:
                 print(" ".join(cmd), flush=True)
             subprocess.check_call(cmd)
@@ -54,6 +76,10 @@ def build(force=False, verbose=True):
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)
+        # the offload bundler leaves its temporaries next to the output
+        for f in os.listdir(PKG):
+            if f.startswith("libfacedet.so."):
+                os.remove(os.path.join(PKG, f))
     return LIB
 
 

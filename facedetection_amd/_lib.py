@@ -54,6 +54,7 @@ class Param(C.Structure):
 # name -> (restype, argtypes); every symbol include/facedet.h declares
 SIGNATURES = {
     "fd_version": (C.c_int, []),
+    "fd_build_id": (C.c_char_p, []),
     "fd_last_error": (C.c_char_p, []),
     "fd_ctx_create": (C.c_int, [C.c_int, C.POINTER(vp)]),
     "fd_ctx_destroy": (None, [vp]),

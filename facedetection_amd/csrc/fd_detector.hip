@@ -56,7 +56,11 @@ struct fd_detector {
     unsigned* clamped = nullptr;         // [1] values outside the fp16 range met while splitting (this pass)
     std::vector<fd::Tap> taps;
     fd::Buf net[fd::NB_COUNT];
-    bool keep_taps = false;              // debugging: snapshot every tapped tensor
+    int keep_mode = 0;                   // snapshot tapped tensors: 0 no; 1 every named tensor, which takes the
+                                         // layer-by-layer kernels (the fused ones do not materialise them all);
+                                         // 2 the tensors the production kernels do materialise, kernel choice unchanged
+    bool keeping() const { return keep_mode != 0; }
+    bool layerwise() const { return keep_mode == 1; }
     int fuse_units = 3;                  // whole-unit kernels of the 64-channel stage: bit 0 identity units, bit 1 the
                                          // projection unit, bit 2 also while tensors are kept for inspection (the
                                          // unit outputs then come from the fused kernels; t1/t2 are not produced);
@@ -299,7 +303,7 @@ struct Plan {
     }
     void tap(const char* name, const float* p, int64_t a, int64_t b, int64_t c, int64_t e) {
         if (dry) return;
-        if (d->keep_taps) {
+        if (d->keeping()) {
             // activation buffers are recycled between layers; keep a private copy of this one
             void* copy = nullptr;
             const size_t bytes = (size_t)(a * b * c * e) * sizeof(float);
@@ -456,7 +460,7 @@ static int run_unit_split(Plan& pl, const Unit& u, const char* name, const void*
     // the projection unit of the 64-channel stage as one kernel: shortcut and main branch are
     // accumulated together, so neither the shortcut tensor nor t1/t2 exist
     bool whole_proj = false;
-    if (u.has_sc && !pl.dry && (!pl.d->keep_taps || (pl.d->fuse_units & 4)) && (pl.d->fuse_units & 2) && y32 && !ysplit)
+    if (u.has_sc && !pl.dry && (!pl.d->layerwise() || (pl.d->fuse_units & 4)) && (pl.d->fuse_units & 2) && y32 && !ysplit)
         FD_TRY(unit_proj_fused_forward(u.s_conv1, u.s_conv2, u.s_conv3, u.s_sc, act, n, h, w, y32, pl.d->clamped,
                                        pl.stream, &whole_proj));
     if (u.has_sc) {
@@ -479,7 +483,7 @@ static int run_unit_split(Plan& pl, const Unit& u, const char* name, const void*
         // identity units of the 64-channel stage run as one kernel (nothing between the unit's
         // input and output goes to HBM); the intermediate tensors exist only for inspection
         bool whole = false;
-        if (!u.has_sc && (!pl.d->keep_taps || (pl.d->fuse_units & 4)) && (pl.d->fuse_units & 1))
+        if (!u.has_sc && (!pl.d->layerwise() || (pl.d->fuse_units & 4)) && (pl.d->fuse_units & 1))
             FD_TRY(unit_fused_forward(u.s_conv1, u.s_conv2, u.s_conv3, xraw, u.bn1_scale, u.bn1_shift, n, h, w, o3,
                                       pl.stream, &whole));
         if (!whole) {
@@ -490,7 +494,7 @@ static int run_unit_split(Plan& pl, const Unit& u, const char* name, const void*
                                               pl.stream));
             }
             bool fused = false;
-            if (!pl.d->keep_taps)
+            if (!pl.d->layerwise())
                 FD_TRY(conv_tail_fused_forward(u.s_conv2, u.s_conv3, t1, n, h, w, res, o3, pl.stream, &fused));
             if (!fused) {
                 FD_TRY(split_conv_forward(u.s_conv2, t1, n, h, w, nullptr, o2, pl.stream));
@@ -508,14 +512,15 @@ static int run_graph_split(Plan& pl, const uint8_t* frames, int B, int H, int W,
                            float** cls_io, float** box_io) {
     fd_detector* d = pl.d;
     const int R = d->prop.post_nms_top_n;
-    const bool keep = d->keep_taps;
+    const bool keep = d->keeping();          // unit outputs are also written as float32 and snapshotted
+    const bool layerwise = d->layerwise();   // ... and the stem, pooling and ROI pooling run as separate kernels
     (void)pl.out();                        // sizes the split-K workspace during the dry run
     const int h1 = d->s_conv0.s.out_h(H), w1 = d->s_conv0.s.out_w(W);
     // Stem and max-pool run as one kernel on a planar staged image.  When intermediate tensors are
     // kept for inspection the two-kernel form is used instead, because only it materialises the
     // convolution output.
     const size_t planar_floats = (size_t)B * H * staged_planar_width(W) * 4;
-    const bool fused_stem = !keep && planar_floats * 4 < (1ull << 31);
+    const bool fused_stem = !layerwise && planar_floats * 4 < (1ull << 31);
     float* staged = pl.buf(NB_STAGED, fused_stem ? planar_floats : (size_t)B * H * W * 4);
     if (!pl.dry) {
         FD_HIP(hipMemsetAsync(d->clamped, 0, sizeof(unsigned), pl.stream));
@@ -548,10 +553,10 @@ static int run_graph_split(Plan& pl, const uint8_t* frames, int B, int H, int W,
                                      nullptr, abuf[0], d->clamped, pl.stream));
         else
             FD_TRY(maxpool_3x3s2_split(c0, B, h1, w1, FILTERS[0], d->stage[0][0].bn1_scale,
-                                       d->stage[0][0].bn1_shift, keep ? xbuf[0] : nullptr, abuf[0], d->clamped,
+                                       d->stage[0][0].bn1_shift, layerwise ? xbuf[0] : nullptr, abuf[0], d->clamped,
                                        pl.stream));
     }
-    if (keep) pl.tap("pool0", xbuf[0], B, h, w, FILTERS[0]);
+    if (layerwise && !fused_stem) pl.tap("pool0", xbuf[0], B, h, w, FILTERS[0]);
     int cur = 0;
     const float* xraw = nullptr;           // raw input of the next unit (NULL when it does not need one)
     for (int s = 0; s < 3; ++s)
@@ -603,14 +608,14 @@ static int run_graph_split(Plan& pl, const uint8_t* frames, int B, int H, int W,
     pl.tap("rois", rois, B, R, 5, 1);
     pl.tap("roi_scores", roi_scores, B, R, 1, 1);
     const int N = B * R;
-    float* pooled = keep ? pl.buf(NB_POOLED, (size_t)N * POOLED * POOLED * FILTERS[3]) : nullptr;
+    float* pooled = layerwise ? pl.buf(NB_POOLED, (size_t)N * POOLED * POOLED * FILTERS[3]) : nullptr;
     const size_t x4 = (size_t)N * POOLED * POOLED * FILTERS[4];
     float* x4buf[2] = {pl.buf(NB_X4A, x4), pl.buf(NB_X4B, x4)};
     float* a4buf[2] = {pl.buf(NB_ACT_A, x4), pl.buf(NB_ACT_B, x4)};
     if (!pl.dry) {
         // feat_split lives in one of the act buffers and is no longer needed: reuse them for stage 4.
         // The float32 pooled tensor is only materialised for inspection.
-        if (keep) {
+        if (layerwise) {
             FD_TRY(roipool_nhwc(feat, B, FILTERS[3], fh, fw, rois, N, POOLED, POOLED, 1.0f / 16.0f, pooled, pl.stream));
             FD_TRY(to_split(pooled, (long long)N * POOLED * POOLED, FILTERS[3], d->stage[3][0].bn1_scale,
                             d->stage[3][0].bn1_shift, a4buf[0], d->clamped, pl.stream));
@@ -620,7 +625,7 @@ static int run_graph_split(Plan& pl, const uint8_t* frames, int B, int H, int W,
                                       pl.stream));
         }
     }
-    if (keep) pl.tap("pooled", pooled, N, POOLED, POOLED, FILTERS[3]);
+    if (layerwise) pl.tap("pooled", pooled, N, POOLED, POOLED, FILTERS[3]);
     h = POOLED; w = POOLED;
     cur = 0;
     xraw = nullptr;
@@ -762,7 +767,8 @@ int fd_detector_set_precision(fd_detector* d, int precision) {
 
 int fd_detector_keep_tensors(fd_detector* d, int keep) {
     FD_REQUIRE(d, "fd_detector_keep_tensors: NULL detector");
-    d->keep_taps = keep != 0;
+    FD_REQUIRE(keep >= 0 && keep <= 2, "fd_detector_keep_tensors: keep must be 0, 1 or 2");
+    d->keep_mode = keep;
     return FD_OK;
 }
 

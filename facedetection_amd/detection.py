@@ -270,9 +270,11 @@ class Detector:
         dets = self.detect_face(img_np, nms_thresh, thresh)
         return dets, np.zeros((dets.shape[0], 0), dtype=np.float32)
 
-    def keep_tensors(self, keep=True):
-        """Debugging: make later forward passes snapshot every named intermediate tensor."""
-        _lib.check(self._lib.fd_detector_keep_tensors(self._h, 1 if keep else 0))
+    def keep_tensors(self, keep=True, production=False):
+        """Debugging: make later forward passes snapshot intermediate tensors.  By default every
+        named tensor, which runs the pass layer by layer; with ``production`` the kernels of an
+        ordinary pass run and the tensors they materialise (unit outputs, feat, ...) are kept."""
+        _lib.check(self._lib.fd_detector_keep_tensors(self._h, (2 if production else 1) if keep else 0))
 
     def tensor(self, name):
         """An intermediate tensor of the last forward pass as a NumPy array (channels-last)."""

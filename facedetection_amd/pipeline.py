@@ -32,28 +32,34 @@ class FramePipeline:
         for d in self.detectors:
             d.reconfigure()
 
-    def detect_device(self, frames, micro_batch=8, nms_thresh=0.3, thresh=0.8, do_round=True):
+    def set_precision(self, precision):
+        for d in self.detectors:
+            d.set_precision(precision)
+
+    def detect_device(self, frames, micro_batch=8, nms_thresh=0.3, thresh=0.8, do_round=True, streams=None):
         """frames uint8 [N,H,W,3] on the GPU -> list, in frame order, of
         (dets [b,R,5], n_dets [b], status [2] = (NaN flag, clamped values)) device tensors per
         micro-batch.  Asynchronous:
         the caller's current stream waits for all side streams before this returns, so work
-        queued on it afterwards (or a synchronize) sees the results."""
+        queued on it afterwards (or a synchronize) sees the results.  ``streams`` limits how many
+        of the pipeline's streams take part (1: everything on the caller's current stream)."""
         outs = []
+        use = self.streams if streams is None else self.streams[:max(1, streams)]
         with torch.cuda.device(self.device):
             cur = torch.cuda.current_stream()
-            if self.streams[0] is None:
+            if use[0] is None or len(use) == 1:
                 for i in range(0, frames.shape[0], micro_batch):
                     outs.append(self.detectors[0].detect_batch_device(frames[i:i + micro_batch], nms_thresh, thresh,
                                                                       do_round))
                 return outs
-            for s in self.streams:
+            for s in use:
                 s.wait_stream(cur)
             for j, i in enumerate(range(0, frames.shape[0], micro_batch)):
-                k = j % len(self.streams)
-                with torch.cuda.stream(self.streams[k]):
+                k = j % len(use)
+                with torch.cuda.stream(use[k]):
                     outs.append(self.detectors[k].detect_batch_device(frames[i:i + micro_batch], nms_thresh, thresh,
                                                                       do_round))
-            for s in self.streams:
+            for s in use:
                 cur.wait_stream(s)
         return outs
 

@@ -35,6 +35,9 @@ typedef struct fd_detector fd_detector;
 
 /* Library ------------------------------------------------------------------ */
 int fd_version(void);
+/* Hash (16 hex digits) of the source files this library was built from; profiles record it so that
+ * a traffic measurement is only ever quoted for the kernel set it was taken on. */
+const char* fd_build_id(void);
 const char* fd_last_error(void);
 /* One context per GPU per host thread.  Synchronous. */
 int fd_ctx_create(int device, fd_ctx** out);
@@ -233,9 +236,16 @@ int fd_detect(fd_detector* det, const uint8_t* frames, int batch, int height, in
  * (device, `capacity` floats) and writes its 4 dimensions; out == NULL only queries the
  * dimensions.  Names: conv0, pool0, stage{1..4}_unit{j}, feat, rpn_out, rois, roi_scores,
  * pooled, flat, cls_prob, bbox_pred.  For parity tests and debugging.  Layer buffers are
- * recycled inside a pass, so by default only conv0, feat and the tensors after it still hold
- * their values afterwards; fd_detector_keep_tensors(det, 1) makes later passes snapshot every
- * named tensor (allocating: debugging only). */
+ * recycled inside a pass, so by default only feat and the tensors after it (not pooled) still hold
+ * their values afterwards.  fd_detector_keep_tensors(det, keep) makes later passes snapshot
+ * tensors (allocating: debugging only):
+ *   keep = 1  every named tensor; the pass then runs layer by layer, because the fused kernels of
+ *             FD_PRECISION_F16X3 (stem+pool, whole residual units, pooling into the split form)
+ *             never materialise conv0, pool0 or pooled;
+ *   keep = 2  every tensor the production kernels materialise (stage{1..4}_unit{j}, feat and what
+ *             follows): kernel selection is exactly that of an ordinary pass, unit outputs are
+ *             additionally written as float32 where an ordinary pass would skip that;
+ *   keep = 0  off. */
 /* The command-line loop's variant (detection.py:110-148): frames are already resized by
  * im_scale (im_info = (height, width, im_scale), so the proposal stage's minimum size scales
  * with it), the tail does not round, and each kept box is mapped back to the source frame as

@@ -1,4 +1,5 @@
-"""bench.py prints exactly one JSON line with the fields the benchmark contract names."""
+"""bench.py prints exactly one JSON line with the fields the benchmark contract names: a float32
+headline, the f16x3 sub-record with its measured error, roofline and cpu_baseline."""
 import json
 import os
 import subprocess
@@ -11,26 +12,55 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def _check_roofline(r):
+    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert key in r, key
+    assert r["bound"] in ("hbm", "mfma") and r["unit"] in ("GB/s", "TFLOP/s")
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    # achieved = algorithmic FLOP per launch / average launch duration, both in the record
+    assert abs(r["achieved"] - r["flop_per_launch"] / (r["avg_launch_ms"] * 1e-3) / 1e12) <= 2e-3 * r["achieved"]
+    # traffic is either a measurement taken on this very kernel set or null with the reason
+    assert r["traffic"] is None or r["traffic"] > 0
+    assert r["traffic_note"]
+
+
 def test_bench_prints_one_json_line_with_the_contract_fields():
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--frames", "16", "--steps", "1", "--warmup", "1"],
-                         cwd=ROOT, capture_output=True, text=True, timeout=600)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--frames", "16", "--steps", "1", "--warmup", "1",
+                          "--check-frames", "1"], cwd=ROOT, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.strip()]
     assert len(lines) == 1, out.stdout[-2000:]
     d = json.loads(lines[0])
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
-                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "f16x3", "accuracy_vs_float64",
+                "n_ranks_seen"):
         assert key in d, key
-    assert d["n_gpus"] == 1 and d["steps"] == 1 and d["warmup"] == 1
+    assert d["n_gpus"] == 1 and d["n_ranks_seen"] == 1 and d["steps"] == 1 and d["warmup"] == 1
     assert d["unit"] == "frames/s" and d["higher_is_better"] is True and d["scaling"] == "weak"
     assert d["vs_baseline"] is None and d["data"] == "synthetic" and "workload" in d["config"]
+    assert d["dtype"] == "f32"                                   # the headline is the reference's arithmetic
     assert d["value"] > 0 and abs(d["value"] - 16 / (d["ms_per_step"] / 1e3)) <= 1e-3 * d["value"]
-    r = d["roofline"]
-    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
-        assert key in r, key
-    assert r["bound"] in ("hbm", "mfma") and r["unit"] in ("GB/s", "TFLOP/s")
-    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    _check_roofline(d["roofline"])
+    assert d["roofline"]["peak"] == 157.3 and d["roofline"]["kernel"].startswith("conv_igemm")
+    a = d["accuracy_vs_float64"]
+    assert a["max_abs_score_err_vs_f64"] <= 1e-4 and a["max_box_err_px"] <= 0.5 and a["clamped_values"] == 0
+    s = d["f16x3"]
+    for key in ("value", "ms_per_step", "roofline", "max_abs_score_err_vs_f64", "max_box_err_px", "clamped_values"):
+        assert key in s, key
+    assert s["value"] > d["value"]
+    assert s["max_abs_score_err_vs_f64"] <= 1e-4 and s["max_box_err_px"] <= 0.5
+    assert s["clamped_values"] == 0 and s["clamped_values_last_timed_step"] == 0
+    _check_roofline(s["roofline"])
     c = d["cpu_baseline"]
     for key in ("value", "unit", "cores", "kind", "sample"):
         assert key in c, key
     assert c["kind"] in ("reference", "port") and c["value"] > 0 and c["cores"] >= 1
+
+
+def test_asking_for_more_gpus_than_visible_fails_loudly():
+    import torch
+    want = torch.cuda.device_count() + 1
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(want), "--steps", "1"], cwd=ROOT,
+                         capture_output=True, text=True, timeout=300,
+                         env={k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")})
+    assert out.returncode == 2 and out.stdout.strip() == "" and "GPU(s) visible" in out.stderr

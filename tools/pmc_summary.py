@@ -10,7 +10,10 @@ WRITE_SIZE is exact for 16-byte-per-lane stores.  Values are averages per launch
 import collections
 import csv
 import json
+import os
 import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
 def agg(path):
@@ -35,7 +38,9 @@ def main():
         short = k.split("(")[0].replace("void ", "")
         out[short] = {"launches": n, "fetch_bytes_per_launch": round(fetch), "write_bytes_per_launch": round(write),
                       "hbm_bytes_per_launch": round(fetch + write)}
-    json.dump({"note": "FETCH_SIZE x2 (gfx950 wide-read correction) + WRITE_SIZE, KiB -> bytes, averaged per launch; "
+    from facedetection_amd import _build
+    json.dump({"csrc_sha16": _build.source_id(),   # the kernel set these counters belong to (fd_build_id of the library)
+               "note": "FETCH_SIZE x2 (gfx950 wide-read correction) + WRITE_SIZE, KiB -> bytes, averaged per launch; "
                        "command: bench.py --frames 16 --steps 1 --warmup 1 --streams 1 (micro-batch 8, 1080p)",
                "kernels": out}, open(sys.argv[3], "w"), indent=1, sort_keys=True)
     for k, v in sorted(out.items(), key=lambda kv: -kv[1]["hbm_bytes_per_launch"] * kv[1]["launches"])[:8]:
