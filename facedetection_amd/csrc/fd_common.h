@@ -39,8 +39,8 @@ void set_error(const char* fmt, ...) __attribute__((format(printf, 1, 2)));
 #define FD_LAUNCH_CHECK() FD_HIP(hipGetLastError())
 
 // Scratch slots.  Each slot is one device allocation that only ever grows; a
-// replaced allocation is parked until the context is destroyed because kernels
-// already queued on the stream may still be using it.
+// replaced allocation is parked (kernels already queued on the stream may still be
+// using it) and freed at the next safe point, see park().
 enum Slot {
     SLOT_SORT_KEYS_A = 0,
     SLOT_SORT_KEYS_B,
@@ -81,7 +81,8 @@ struct Buf {
 struct fd_ctx {
     int device = 0;
     fd::Buf slots[fd::SLOT_COUNT];
-    std::vector<void*> parked;
+    std::vector<fd::Buf> parked;       // replaced allocations that queued kernels may still use
+    size_t parked_bytes = 0;
     int64_t bytes = 0;
 };
 
@@ -89,6 +90,12 @@ namespace fd {
 
 // Returns a device buffer of at least `bytes` for `slot` (contents undefined).
 int scratch(fd_ctx* ctx, Slot slot, size_t bytes, void** out);
+
+// Hands a replaced allocation to the context.  It is freed at the next safe point: once the parked
+// allocations exceed PARK_LIMIT bytes the device is synchronised (nothing queued can still use
+// them) and all of them are released, so a stream of growing shapes does not accumulate memory.
+constexpr size_t PARK_LIMIT = size_t(256) << 20;
+int park(fd_ctx* ctx, void* ptr, size_t bytes);
 
 template <typename T>
 inline int scratch_as(fd_ctx* ctx, Slot slot, size_t count, T** out) {

@@ -682,7 +682,7 @@ static int forward(fd_detector* d, const uint8_t* frames, int B, int H, int W, f
                 set_error("activation buffer %d: hipMalloc(%zu) failed: %s", i, want, hipGetErrorString(e));
                 return FD_ERR_HIP;
             }
-            if (b.ptr) d->ctx->parked.push_back(b.ptr);   // kernels in flight may still read it
+            if (b.ptr) FD_TRY(park(d->ctx, b.ptr, b.cap));   // kernels in flight may still read it
             b.ptr = p;
             b.cap = want;
             d->ctx->bytes += (int64_t)want;
