@@ -66,6 +66,7 @@ SIGNATURES = {
     "fd_bbox_pred_f64": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, vp, vp]),
     "fd_clip_boxes_f64": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_double, C.c_double, vp]),
     "fd_nms_f32": (C.c_int, [vp, vp, C.c_int, C.c_float, vp, vp, vp]),
+    "fd_nms_f32_noalloc": (C.c_int, [vp, C.c_int, C.c_float, vp, vp, vp]),
     "fd_nms_f64": (C.c_int, [vp, vp, C.c_int, C.c_double, vp, vp, vp]),
     "fd_proposal": (C.c_int, [vp, C.POINTER(ProposalCfg), vp, vp, c_f32p, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp]),
     "fd_roipool": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_float, vp, vp]),

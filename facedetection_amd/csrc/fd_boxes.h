@@ -56,4 +56,8 @@ int roipool_nhwc_split(const float* data, int batch, int channels, int height, i
                        int num_rois, int pooled_h, int pooled_w, float spatial_scale, const float* bn_scale,
                        const float* bn_shift, void* out_split, unsigned* clamped, hipStream_t stream);
 
+// Resolves, for `device` (the current device), the address of the fixed workspace that
+// fd_nms_f32_noalloc uses; called from fd_ctx_create so that the entry point itself never has to.
+int noalloc_init_device(int device);
+
 }  // namespace fd

@@ -13,10 +13,13 @@
 #include <cfloat>
 #include <cmath>
 #include <cstring>
+#include <mutex>
 
 #pragma clang fp contract(off)
 
 namespace fd {
+
+constexpr long long ceil_div_c(long long a, long long b) { return (a + b - 1) / b; }
 
 // ---------------------------------------------------------------------------------
 // Sort keys: ascending key order == descending score order.
@@ -157,9 +160,10 @@ __global__ __launch_bounds__(256) void sort_small_kernel(K* __restrict__ keys, u
     }
 }
 
+// `hist`: nseg * 256 * ceil(n / SORT_TILE) counters (unused for n <= SORT_SMALL_MAX)
 template <typename K>
-static int sort_pairs(fd_ctx* ctx, K* keys_a, uint32_t* vals_a, K* keys_b, uint32_t* vals_b, int n, int nseg,
-                      hipStream_t stream) {
+static int sort_pairs_ws(K* keys_a, uint32_t* vals_a, K* keys_b, uint32_t* vals_b, int n, int nseg, uint32_t* hist,
+                         hipStream_t stream) {
     if (n <= 0 || nseg <= 0) return FD_OK;
     if (n <= SORT_SMALL_MAX) {
         ProfScope scope(stream, "sort_small", 0.0, 2.0 * (sizeof(K) + 4.0) * n * nseg);
@@ -168,8 +172,6 @@ static int sort_pairs(fd_ctx* ctx, K* keys_a, uint32_t* vals_a, K* keys_b, uint3
         return FD_OK;
     }
     const int nblk = ceil_div(n, SORT_TILE);
-    uint32_t* hist = nullptr;
-    FD_TRY(scratch_as(ctx, SLOT_SORT_HIST, (size_t)nseg * 256 * nblk, &hist));
     dim3 grid(nblk, nseg);
     ProfScope scope(stream, "radix_sort", 0.0, (double)sizeof(K) * 8 / 8 * 2.0 * (sizeof(K) + 4.0) * n * nseg);
     K* src_k = keys_a;
@@ -186,6 +188,15 @@ static int sort_pairs(fd_ctx* ctx, K* keys_a, uint32_t* vals_a, K* keys_b, uint3
         uint32_t* tv = src_v; src_v = dst_v; dst_v = tv;
     }
     return FD_OK;   // an even number of passes: the result is back in (keys_a, vals_a)
+}
+
+template <typename K>
+static int sort_pairs(fd_ctx* ctx, K* keys_a, uint32_t* vals_a, K* keys_b, uint32_t* vals_b, int n, int nseg,
+                      hipStream_t stream) {
+    uint32_t* hist = nullptr;
+    if (n > SORT_SMALL_MAX && nseg > 0)
+        FD_TRY(scratch_as(ctx, SLOT_SORT_HIST, (size_t)nseg * 256 * ceil_div(n, SORT_TILE), &hist));
+    return sort_pairs_ws<K>(keys_a, vals_a, keys_b, vals_b, n, nseg, hist, stream);
 }
 
 int sort_pairs_u32(fd_ctx* ctx, uint32_t* ka, uint32_t* va, uint32_t* kb, uint32_t* vb, int n, int nseg,
@@ -403,20 +414,14 @@ __global__ __launch_bounds__(256) void nms_spread_kernel(const uint64_t* __restr
 // Limited by the size of one mask panel (4096 x cap / 8 bytes) and by 32-bit indexing.
 constexpr long long NMS_MAX_CAND = 1 << 20;
 
+// `mask`: nseg * panel_rows * words words (one row panel), `bits`: nseg * words * 2 words
+// (removed_g | keptbits), with words = ceil(cap / 64), panel_rows = 64 * min(words, NMS_PANEL_CHUNKS).
 template <typename T>
-int nms_sorted(fd_ctx* ctx, const T* cand_boxes, int32_t* counters, int cap, int nseg, T thresh, int max_keep,
-               int32_t* keep, hipStream_t stream) {
-    if (cap <= 0 || nseg <= 0) return FD_OK;
-    if (cap > NMS_MAX_CAND) {
-        set_error("nms: %d candidates per image exceed the limit of %lld", cap, NMS_MAX_CAND);
-        return FD_ERR_LIMIT;
-    }
+static int nms_sorted_ws(const T* cand_boxes, int32_t* counters, int cap, int nseg, T thresh, int max_keep,
+                         int32_t* keep, uint64_t* mask, uint64_t* bits, hipStream_t stream) {
     const int words = ceil_div(cap, 64);
     const int panel_chunks = words < NMS_PANEL_CHUNKS ? words : NMS_PANEL_CHUNKS;
     const int panel_rows = panel_chunks * 64;
-    uint64_t *mask = nullptr, *bits = nullptr;
-    FD_TRY(scratch_as(ctx, SLOT_NMS_MASK, (size_t)nseg * panel_rows * words, &mask));
-    FD_TRY(scratch_as(ctx, SLOT_MISC2, (size_t)nseg * words * 2, &bits));     // removed_g | keptbits
     uint64_t* removed_g = bits;
     uint64_t* keptbits = bits + (size_t)nseg * words;
     const bool multi = words > panel_chunks;
@@ -448,6 +453,22 @@ int nms_sorted(fd_ctx* ctx, const T* cand_boxes, int32_t* counters, int cap, int
         }
     }
     return FD_OK;
+}
+
+template <typename T>
+int nms_sorted(fd_ctx* ctx, const T* cand_boxes, int32_t* counters, int cap, int nseg, T thresh, int max_keep,
+               int32_t* keep, hipStream_t stream) {
+    if (cap <= 0 || nseg <= 0) return FD_OK;
+    if (cap > NMS_MAX_CAND) {
+        set_error("nms: %d candidates per image exceed the limit of %lld", cap, NMS_MAX_CAND);
+        return FD_ERR_LIMIT;
+    }
+    const int words = ceil_div(cap, 64);
+    const int panel_chunks = words < NMS_PANEL_CHUNKS ? words : NMS_PANEL_CHUNKS;
+    uint64_t *mask = nullptr, *bits = nullptr;
+    FD_TRY(scratch_as(ctx, SLOT_NMS_MASK, (size_t)nseg * panel_chunks * 64 * words, &mask));
+    FD_TRY(scratch_as(ctx, SLOT_MISC2, (size_t)nseg * words * 2, &bits));
+    return nms_sorted_ws<T>(cand_boxes, counters, cap, nseg, thresh, max_keep, keep, mask, bits, stream);
 }
 
 template int nms_sorted<float>(fd_ctx*, const float*, int32_t*, int, int, float, int, int32_t*, hipStream_t);
@@ -732,6 +753,36 @@ __global__ __launch_bounds__(256) void nms_finish_kernel(const int32_t* __restri
     if (i < nk) keep_out[i] = cand_index[keep_ranks[i]];
 }
 
+// Every buffer nms(dets, thresh) needs beyond its arguments, for one call of n boxes.
+template <typename T, typename K>
+struct NmsWorkspace {
+    T *boxes, *cand_boxes;            // n * 4 each
+    K *ka, *kb;                       // n each
+    uint32_t *va, *vb, *hist;         // n, n, 256 * ceil(n / SORT_TILE)
+    int32_t *counters, *cand_index, *keep;   // CNT_STRIDE, n, n
+    uint64_t *mask, *bits;            // one row panel; 2 * ceil(n / 64)
+};
+
+// The launch sequence of nms(dets, thresh) on a prepared workspace: allocates nothing.
+template <typename T, typename K>
+static int nms_standalone_ws(const NmsWorkspace<T, K>& w, const T* dets, int n, T thresh, int32_t* keep_out,
+                             int32_t* n_keep, hipStream_t stream) {
+    const int nb = ceil_div(n, 256);
+    hipLaunchKernelGGL((nms_prepare_kernel<T, K>), dim3(nb), dim3(256), 0, stream, dets, n, w.boxes, w.ka, w.va);
+    FD_LAUNCH_CHECK();
+    hipLaunchKernelGGL(set_counters_kernel, dim3(1), dim3(256), 0, stream, w.counters, n);
+    FD_LAUNCH_CHECK();
+    FD_TRY((sort_pairs_ws<K>(w.ka, w.va, w.kb, w.vb, n, 1, w.hist, stream)));
+    hipLaunchKernelGGL(gather_candidates_kernel<T>, dim3(nb, 1), dim3(256), 0, stream, w.va, w.boxes,
+                       (const float*)nullptr, n, n, w.counters, w.cand_boxes, (float*)nullptr, w.cand_index);
+    FD_LAUNCH_CHECK();
+    FD_TRY(nms_sorted_ws<T>(w.cand_boxes, w.counters, n, 1, thresh, 0, w.keep, w.mask, w.bits, stream));
+    hipLaunchKernelGGL(nms_finish_kernel, dim3(nb), dim3(256), 0, stream, w.keep, w.cand_index, w.counters, n, keep_out,
+                       n_keep);
+    FD_LAUNCH_CHECK();
+    return FD_OK;
+}
+
 template <typename T, typename K>
 static int nms_standalone(fd_ctx* ctx, const T* dets, int n, T thresh, int32_t* keep_out, int32_t* n_keep,
                           hipStream_t stream) {
@@ -745,32 +796,67 @@ static int nms_standalone(fd_ctx* ctx, const T* dets, int n, T thresh, int32_t* 
         set_error("nms: %d boxes exceed the limit of %lld", n, NMS_MAX_CAND);
         return FD_ERR_LIMIT;
     }
-    T *boxes = nullptr, *cand_boxes = nullptr;
-    K *ka = nullptr, *kb = nullptr;
-    uint32_t *va = nullptr, *vb = nullptr;
-    int32_t *counters = nullptr, *cand_index = nullptr, *keep = nullptr;
-    FD_TRY(scratch_as(ctx, SLOT_BOXES, (size_t)n * 4, &boxes));
-    FD_TRY(scratch_as(ctx, SLOT_SORT_KEYS_A, (size_t)n, &ka));
-    FD_TRY(scratch_as(ctx, SLOT_SORT_KEYS_B, (size_t)n, &kb));
-    FD_TRY(scratch_as(ctx, SLOT_SORT_VALS_A, (size_t)n, &va));
-    FD_TRY(scratch_as(ctx, SLOT_SORT_VALS_B, (size_t)n, &vb));
-    FD_TRY(scratch_as(ctx, SLOT_COUNTERS, (size_t)CNT_STRIDE, &counters));
-    FD_TRY(scratch_as(ctx, SLOT_CAND_BOXES, (size_t)n * 4, &cand_boxes));
-    FD_TRY(scratch_as(ctx, SLOT_CAND_INDEX, (size_t)n, &cand_index));
-    FD_TRY(scratch_as(ctx, SLOT_KEEP, (size_t)n, &keep));
-    const int nb = ceil_div(n, 256);
-    hipLaunchKernelGGL((nms_prepare_kernel<T, K>), dim3(nb), dim3(256), 0, stream, dets, n, boxes, ka, va);
-    FD_LAUNCH_CHECK();
-    hipLaunchKernelGGL(set_counters_kernel, dim3(1), dim3(256), 0, stream, counters, n);
-    FD_LAUNCH_CHECK();
-    FD_TRY((sort_pairs<K>(ctx, ka, va, kb, vb, n, 1, stream)));
-    hipLaunchKernelGGL(gather_candidates_kernel<T>, dim3(nb, 1), dim3(256), 0, stream, va, boxes,
-                       (const float*)nullptr, n, n, counters, cand_boxes, (float*)nullptr, cand_index);
-    FD_LAUNCH_CHECK();
-    FD_TRY(nms_sorted<T>(ctx, cand_boxes, counters, n, 1, thresh, 0, keep, stream));
-    hipLaunchKernelGGL(nms_finish_kernel, dim3(nb), dim3(256), 0, stream, keep, cand_index, counters, n, keep_out,
-                       n_keep);
-    FD_LAUNCH_CHECK();
+    NmsWorkspace<T, K> w;
+    const int words = ceil_div(n, 64);
+    const int panel_chunks = words < NMS_PANEL_CHUNKS ? words : NMS_PANEL_CHUNKS;
+    FD_TRY(scratch_as(ctx, SLOT_BOXES, (size_t)n * 4, &w.boxes));
+    FD_TRY(scratch_as(ctx, SLOT_SORT_KEYS_A, (size_t)n, &w.ka));
+    FD_TRY(scratch_as(ctx, SLOT_SORT_KEYS_B, (size_t)n, &w.kb));
+    FD_TRY(scratch_as(ctx, SLOT_SORT_VALS_A, (size_t)n, &w.va));
+    FD_TRY(scratch_as(ctx, SLOT_SORT_VALS_B, (size_t)n, &w.vb));
+    FD_TRY(scratch_as(ctx, SLOT_SORT_HIST, (size_t)256 * ceil_div(n, SORT_TILE), &w.hist));
+    FD_TRY(scratch_as(ctx, SLOT_COUNTERS, (size_t)CNT_STRIDE, &w.counters));
+    FD_TRY(scratch_as(ctx, SLOT_CAND_BOXES, (size_t)n * 4, &w.cand_boxes));
+    FD_TRY(scratch_as(ctx, SLOT_CAND_INDEX, (size_t)n, &w.cand_index));
+    FD_TRY(scratch_as(ctx, SLOT_KEEP, (size_t)n, &w.keep));
+    FD_TRY(scratch_as(ctx, SLOT_NMS_MASK, (size_t)panel_chunks * 64 * words, &w.mask));
+    FD_TRY(scratch_as(ctx, SLOT_MISC2, (size_t)words * 2, &w.bits));
+    return nms_standalone_ws<T, K>(w, dets, n, thresh, keep_out, n_keep, stream);
+}
+
+// ---------------------------------------------------------------------------------
+// nms(dets, thresh) for callers that must not allocate: the workspace is a fixed device array of
+// this library, one copy per GPU, carved up for at most NOALLOC_MAX_BOXES boxes (one mask panel).
+// ---------------------------------------------------------------------------------
+constexpr int NOALLOC_MAX_BOXES = NMS_PANEL_ROWS;                       // 4096
+constexpr size_t NOALLOC_MASK_BYTES = (size_t)NOALLOC_MAX_BOXES * (NOALLOC_MAX_BOXES / 64) * 8;   // 2 MiB
+constexpr size_t NOALLOC_VEC = (size_t)NOALLOC_MAX_BOXES * 4;          // one 32-bit value per box
+constexpr size_t NOALLOC_OFF_BOXES = NOALLOC_MASK_BYTES;               // 4 floats per box
+constexpr size_t NOALLOC_OFF_CAND = NOALLOC_OFF_BOXES + 4 * NOALLOC_VEC;
+constexpr size_t NOALLOC_OFF_KA = NOALLOC_OFF_CAND + 4 * NOALLOC_VEC;
+constexpr size_t NOALLOC_OFF_KB = NOALLOC_OFF_KA + NOALLOC_VEC;
+constexpr size_t NOALLOC_OFF_VA = NOALLOC_OFF_KB + NOALLOC_VEC;
+constexpr size_t NOALLOC_OFF_VB = NOALLOC_OFF_VA + NOALLOC_VEC;
+constexpr size_t NOALLOC_OFF_INDEX = NOALLOC_OFF_VB + NOALLOC_VEC;
+constexpr size_t NOALLOC_OFF_KEEP = NOALLOC_OFF_INDEX + NOALLOC_VEC;
+constexpr size_t NOALLOC_OFF_HIST = NOALLOC_OFF_KEEP + NOALLOC_VEC;    // 256 * ceil(4096 / 2048) counters
+constexpr size_t NOALLOC_OFF_BITS = NOALLOC_OFF_HIST + 256 * 2 * 4;    // 2 * 64 words
+constexpr size_t NOALLOC_OFF_COUNTERS = NOALLOC_OFF_BITS + 2 * 64 * 8;
+constexpr size_t NOALLOC_BYTES = NOALLOC_OFF_COUNTERS + 256;
+static_assert(NOALLOC_MAX_BOXES <= NMS_PANEL_ROWS && ceil_div_c(NOALLOC_MAX_BOXES, SORT_TILE) == 2, "workspace plan");
+
+}  // namespace fd
+
+// File scope, outside the namespace (which already has a function of this name).
+static __device__ __align__(256) unsigned char scratch[fd::NOALLOC_BYTES];
+
+namespace fd {
+
+// Device address of `scratch` on each GPU (every GPU holds its own copy at its own address).  In
+// host code the array's name is only a handle for hipGetSymbolAddress, never an address.
+constexpr int NOALLOC_MAX_DEVICES = 64;
+static unsigned char* g_scratch_ptr[NOALLOC_MAX_DEVICES];
+static std::mutex g_scratch_mu;
+
+// Resolves the array's address on `device` (which must be the current device); idempotent.
+int noalloc_init_device(int device) {
+    FD_REQUIRE(device >= 0 && device < NOALLOC_MAX_DEVICES, "no-alloc nms: device index %d out of range", device);
+    std::lock_guard<std::mutex> lock(g_scratch_mu);
+    if (g_scratch_ptr[device]) return FD_OK;
+    void* p = nullptr;
+    FD_HIP(hipGetSymbolAddress(&p, HIP_SYMBOL(::scratch)));
+    FD_REQUIRE(p != nullptr, "no-alloc nms: hipGetSymbolAddress returned a null address");
+    g_scratch_ptr[device] = static_cast<unsigned char*>(p);
     return FD_OK;
 }
 
@@ -1078,6 +1164,43 @@ int fd_clip_boxes_f64(fd_ctx* ctx, double* boxes, int n, int num_classes, double
 
 int fd_nms_f32(fd_ctx* ctx, const float* dets, int n, float thresh, int32_t* keep, int32_t* n_keep, void* stream) {
     return fd::nms_standalone<float, uint32_t>(ctx, dets, n, thresh, keep, n_keep, fd::as_stream(stream));
+}
+
+int fd_nms_f32_noalloc(const float* dets, int n, float thresh, int32_t* keep, int32_t* n_keep, void* stream) {
+    using namespace fd;
+    FD_REQUIRE(n_keep && n >= 0, "fd_nms_f32_noalloc: bad arguments");
+    if (n > NOALLOC_MAX_BOXES) {
+        set_error("fd_nms_f32_noalloc: %d boxes exceed the fixed workspace's limit of %d; use fd_nms_f32", n,
+                  NOALLOC_MAX_BOXES);
+        return FD_ERR_LIMIT;
+    }
+    hipStream_t st = as_stream(stream);
+    if (n == 0) {
+        FD_HIP(hipMemsetAsync(n_keep, 0, sizeof(int32_t), st));
+        return FD_OK;
+    }
+    FD_REQUIRE(dets && keep, "fd_nms_f32_noalloc: NULL dets / keep");
+    int device = -1;
+    FD_HIP(hipGetDevice(&device));
+    FD_REQUIRE(device >= 0 && device < NOALLOC_MAX_DEVICES, "fd_nms_f32_noalloc: device index %d out of range", device);
+    if (!g_scratch_ptr[device]) FD_TRY(noalloc_init_device(device));       // first call on this GPU
+    unsigned char* base = g_scratch_ptr[device];
+    NmsWorkspace<float, uint32_t> w;
+    w.mask = reinterpret_cast<uint64_t*>(base);
+    w.boxes = reinterpret_cast<float*>(base + NOALLOC_OFF_BOXES);
+    w.cand_boxes = reinterpret_cast<float*>(base + NOALLOC_OFF_CAND);
+    w.ka = reinterpret_cast<uint32_t*>(base + NOALLOC_OFF_KA);
+    w.kb = reinterpret_cast<uint32_t*>(base + NOALLOC_OFF_KB);
+    w.va = reinterpret_cast<uint32_t*>(base + NOALLOC_OFF_VA);
+    w.vb = reinterpret_cast<uint32_t*>(base + NOALLOC_OFF_VB);
+    w.cand_index = reinterpret_cast<int32_t*>(base + NOALLOC_OFF_INDEX);
+    w.keep = reinterpret_cast<int32_t*>(base + NOALLOC_OFF_KEEP);
+    w.hist = reinterpret_cast<uint32_t*>(base + NOALLOC_OFF_HIST);
+    w.bits = reinterpret_cast<uint64_t*>(base + NOALLOC_OFF_BITS);
+    w.counters = reinterpret_cast<int32_t*>(base + NOALLOC_OFF_COUNTERS);
+    // Nothing in the workspace has to start at zero: the counters are set by the first kernels, the
+    // histogram, keys, mask words and kept bits a call reads are all written by that call first.
+    return nms_standalone_ws<float, uint32_t>(w, dets, n, thresh, keep, n_keep, st);
 }
 
 int fd_nms_f64(fd_ctx* ctx, const double* dets, int n, double thresh, int32_t* keep, int32_t* n_keep, void* stream) {

@@ -90,6 +90,18 @@ int fd_clip_boxes_f64(fd_ctx* ctx, double* boxes, int n, int num_classes, double
 int fd_nms_f32(fd_ctx* ctx, const float* dets, int n, float thresh, int32_t* keep, int32_t* n_keep, void* stream);
 int fd_nms_f64(fd_ctx* ctx, const double* dets, int n, double thresh, int32_t* keep, int32_t* n_keep, void* stream);
 
+/* fd_nms_f32 without any allocation.  No counterpart in the reference: it exists for callers that
+ * cannot allocate device memory at the point of the call -- code under HIP graph capture, tight
+ * serving loops, harnesses that forbid hipMalloc.  Same arguments, same results and same kernels as
+ * fd_nms_f32 for n <= 4096 boxes (FD_ERR_LIMIT beyond); no context: the sort buffers, the
+ * suppression mask and the counters live in a fixed 2.3 MB device array of the library, one per
+ * GPU, which every GPU the library runs on holds until the process ends.  Operates on the CURRENT
+ * device (dets, keep, n_keep and stream must belong to it).  The array's address is resolved by
+ * fd_ctx_create for its device, otherwise by the first call on a device (not under graph capture
+ * then).  All calls on one GPU share that array: calls that overlap on one GPU (two streams, two
+ * host threads) race -- serialise them.  The event profiler must be off (it creates events). */
+int fd_nms_f32_noalloc(const float* dets, int n, float thresh, int32_t* keep, int32_t* n_keep, void* stream);
+
 /* RPN proposal operator --------------------------------------------------------
  * mx.symbol.contrib.Proposal(cls_prob, bbox_pred, im_info, ...) as called at
  * symbol/faster_rcnn.py:98-102, computed with the steps of its in-tree Python twin
