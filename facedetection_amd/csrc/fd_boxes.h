@@ -54,7 +54,8 @@ int roipool_nhwc(const float* data, int batch, int channels, int height, int wid
 // `clamped`: device counter of values outside the fp16 range met while splitting, or NULL.
 int roipool_nhwc_split(const float* data, int batch, int channels, int height, int width, const float* rois,
                        int num_rois, int pooled_h, int pooled_w, float spatial_scale, const float* bn_scale,
-                       const float* bn_shift, void* out_split, unsigned* clamped, hipStream_t stream);
+                       const float* bn_shift, void* out_split, unsigned* clamped, hipStream_t stream,
+                       bool f32 = false);   // f32: plain float32 activated values instead of the split form
 
 // Resolves, for `device` (the current device), the address of the fixed workspace that
 // fd_nms_f32_noalloc uses; called from fd_ctx_create so that the entry point itself never has to.

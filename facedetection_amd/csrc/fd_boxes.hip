@@ -1067,7 +1067,8 @@ __global__ __launch_bounds__(128) void roipool_nhwc_split_kernel(const float* __
                                                                 int W, const float* __restrict__ rois, int PH, int PW,
                                                                 float scale, const float* __restrict__ bn_scale,
                                                                 const float* __restrict__ bn_shift,
-                                                                uint8_t* __restrict__ out, unsigned* __restrict__ clamped) {
+                                                                uint8_t* __restrict__ out, unsigned* __restrict__ clamped,
+                                                                int f32) {
     const int bin = blockIdx.x, n = blockIdx.y;
     const RoiBin r = roi_bin(rois + (size_t)n * 5, scale, bin / PW, bin % PW, PH, PW, H, W, batch);
     uint8_t* o = out + ((size_t)n * PH * PW + bin) * C * 4;
@@ -1096,6 +1097,12 @@ __global__ __launch_bounds__(128) void roipool_nhwc_split_kernel(const float* __
             m0[j] = fmaxf(__builtin_fmaf(m0[j], s0[j], t0[j]), 0.f);
             m1[j] = fmaxf(__builtin_fmaf(m1[j], s1[j], t1[j]), 0.f);
         }
+        if (f32) {
+            float* ap = reinterpret_cast<float*>(o) + c8 * 8;
+            *reinterpret_cast<f32x4*>(ap) = m0;
+            *reinterpret_cast<f32x4*>(ap + 4) = m1;
+            continue;
+        }
         f16x8 hi, lo;
         split8(m0, m1, hi, lo, bad);
         uint8_t* sp = o + split_offset(c8 * 8);
@@ -1107,14 +1114,14 @@ __global__ __launch_bounds__(128) void roipool_nhwc_split_kernel(const float* __
 
 int roipool_nhwc_split(const float* data, int batch, int C, int H, int W, const float* rois, int num_rois, int PH,
                        int PW, float scale, const float* bn_scale, const float* bn_shift, void* out, unsigned* clamped,
-                       hipStream_t stream) {
+                       hipStream_t stream, bool f32) {
     FD_REQUIRE(data && rois && out && bn_scale && bn_shift, "roipool: NULL argument");
     FD_REQUIRE(C % 32 == 0 && C > 0, "roipool (split output): channel count %d must be a multiple of 32", C);
     FD_REQUIRE(PH > 0 && PW > 0, "roipool (split output): bad bin grid");
     if (num_rois <= 0) return FD_OK;
     ProfScope scope(stream, "roipool", 0.0, 2.0 * 4.0 * (double)num_rois * PH * PW * C);
     hipLaunchKernelGGL(roipool_nhwc_split_kernel, dim3(PH * PW, num_rois), dim3(128), 0, stream, data, batch, C, H, W,
-                       rois, PH, PW, scale, bn_scale, bn_shift, static_cast<uint8_t*>(out), clamped);
+                       rois, PH, PW, scale, bn_scale, bn_shift, static_cast<uint8_t*>(out), clamped, f32 ? 1 : 0);
     FD_LAUNCH_CHECK();
     return FD_OK;
 }

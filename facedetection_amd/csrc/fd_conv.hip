@@ -16,8 +16,10 @@
 // Pipeline: global loads of K-step t+1 are issued into registers before the MFMAs of step
 // t and written to the other LDS buffer after them; one barrier per K-step.
 #include "fd_conv.h"
+#include "fd_conv_split.h"
 
 #include <cfloat>
+#include <cstdlib>
 #include <string>
 
 namespace fd {
@@ -478,6 +480,17 @@ int fd_conv2d(fd_ctx* ctx, const float* x_nhwc, int batch, int height, int width
     FD_TRY(fd::scratch_as(ctx, fd::SLOT_MISC0, p.s.packed_floats(), &packed));
     FD_TRY(fd::pack_conv_weights(w_oihw, cin, p.s, nullptr, packed, fd::as_stream(stream)));
     p.w = packed; p.bias = bias; p.pre_scale = pre_scale; p.pre_shift = pre_shift; p.relu = relu;
+    // Layers without an input BatchNorm take the direct-to-LDS kernel, like the detector's float32 pass
+    // (FD_F32_GLDS=0 keeps the register-staged kernel for comparisons).
+    static const bool glds = !(getenv("FD_F32_GLDS") && atoi(getenv("FD_F32_GLDS")) == 0);
+    const size_t x_bytes = (size_t)batch * height * width * cin * 4;
+    if (glds && !pre_scale && x_bytes < (1ull << 31) && p.s.packed_floats() * 4 < (1ull << 31) && cout % 8 == 0) {
+        fd::SplitConvParams sp;
+        sp.s = p.s; sp.w = packed; sp.w_inv_scale = 1.f; sp.bias = bias; sp.relu = relu; sp.f32 = true;
+        fd::SplitConvOut o;
+        o.y32 = y_nhwc;
+        return fd::split_conv_forward(sp, x_nhwc, batch, height, width, residual, o, fd::as_stream(stream));
+    }
     return fd::conv_forward(p, x_nhwc, batch, height, width, residual, y_nhwc, fd::as_stream(stream));
 }
 

@@ -251,6 +251,7 @@ __global__ __launch_bounds__(256, 2) void conv_tail_fused_kernel(SplitKArgs a, S
 int conv_tail_fused_forward(const SplitConvParams& p2, const SplitConvParams& p3, const void* x_split, int batch, int h,
                             int w, const float* residual, const SplitConvOut& out, hipStream_t stream, bool* taken) {
     *taken = false;
+    if (p2.f32 || p3.f32) return FD_OK;          // split operands only
     const ConvShape &s2 = p2.s, &s3 = p3.s;
     if (!(s2.cin == 64 && s2.cout == 64 && s2.kh == 3 && s2.kw == 3 && s2.kwp == 3 && s2.stride == 1 && s2.pad == 1 &&
           p2.relu && s3.cin == 64 && s3.kh == 1 && s3.kw == 1 && s3.stride == 1 && s3.pad == 0 && s3.cout % 64 == 0))
@@ -266,7 +267,7 @@ int conv_tail_fused_forward(const SplitConvParams& p2, const SplitConvParams& p3
     a.pre_scale = a.pre_shift = nullptr; a.w_inv_scale = p2.w_inv_scale;
     a.H = h; a.W = w; a.Cin = 64; a.Ho = h; a.Wo = w; a.Cout = 64; a.KW = 3; a.stride = 1; a.pad = 1; a.K = s2.k();
     a.M = (int)m_ll; a.relu = 1; a.tiles_n = 1;
-    a.ksplit = 1; a.kchunk = a.K / SBK; a.partial = nullptr; a.clamped = out.clamped;
+    a.ksplit = 1; a.kchunk = a.K / SBK; a.partial = nullptr; a.clamped = out.clamped; a.f32 = 0;
     c = a;
     c.x = nullptr; c.w = static_cast<const uint8_t*>(p3.w); c.bias = p3.bias; c.res = residual; c.y32 = out.y32;
     c.ysplit = static_cast<uint8_t*>(out.ysplit); c.post_scale = out.post_scale; c.post_shift = out.post_shift;
@@ -635,6 +636,7 @@ int unit_fused_forward(const SplitConvParams& p1, const SplitConvParams& p2, con
                        const float* pre_scale, const float* pre_shift, int batch, int h, int w, const SplitConvOut& out,
                        hipStream_t stream, bool* taken) {
     *taken = false;
+    if (p1.f32 || p2.f32 || p3.f32) return FD_OK;   // split operands only
     const ConvShape &s1 = p1.s, &s2 = p2.s, &s3 = p3.s;
     if (!(s1.cin == 256 && s1.cout == 64 && s1.kh == 1 && s1.kw == 1 && s1.stride == 1 && s1.pad == 0 && p1.relu &&
           s2.cin == 64 && s2.cout == 64 && s2.kh == 3 && s2.kw == 3 && s2.kwp == 3 && s2.stride == 1 && s2.pad == 1 &&
@@ -651,7 +653,7 @@ int unit_fused_forward(const SplitConvParams& p1, const SplitConvParams& p2, con
     a.pre_scale = pre_scale; a.pre_shift = pre_shift; a.w_inv_scale = p1.w_inv_scale;
     a.H = h; a.W = w; a.Cin = 256; a.Ho = h; a.Wo = w; a.Cout = 64; a.KW = 1; a.stride = 1; a.pad = 0; a.K = 256;
     a.M = (int)m_ll; a.relu = 1; a.tiles_n = 1; a.ksplit = 1; a.kchunk = a.K / SBK; a.partial = nullptr;
-    a.clamped = out.clamped;
+    a.clamped = out.clamped; a.f32 = 0;
     u.c1 = a;
     u.c2 = a;
     u.c2.x = nullptr; u.c2.w = static_cast<const uint8_t*>(p2.w); u.c2.bias = p2.bias; u.c2.pre_scale = u.c2.pre_shift = nullptr;
@@ -1047,6 +1049,7 @@ int unit_proj_fused_forward(const SplitConvParams& p1, const SplitConvParams& p2
                             const SplitConvParams& psc, const void* act, int batch, int h, int w, float* y32,
                             unsigned* clamped, hipStream_t stream, bool* taken) {
     *taken = false;
+    if (p1.f32 || p2.f32 || p3.f32 || psc.f32) return FD_OK;   // split operands only
     const ConvShape &s1 = p1.s, &s2 = p2.s, &s3 = p3.s, &ss = psc.s;
     if (!(s1.cin == 64 && s1.cout == 64 && s1.kh == 1 && s1.kw == 1 && s1.stride == 1 && s1.pad == 0 && p1.relu &&
           s2.cin == 64 && s2.cout == 64 && s2.kh == 3 && s2.kw == 3 && s2.kwp == 3 && s2.stride == 1 && s2.pad == 1 &&
@@ -1064,7 +1067,7 @@ int unit_proj_fused_forward(const SplitConvParams& p1, const SplitConvParams& p2
     a.bias = p1.bias; a.res = nullptr; a.y32 = nullptr; a.ysplit = nullptr; a.post_scale = a.post_shift = nullptr;
     a.pre_scale = a.pre_shift = nullptr; a.w_inv_scale = p1.w_inv_scale;
     a.H = h; a.W = w; a.Cin = 64; a.Ho = h; a.Wo = w; a.Cout = 64; a.KW = 1; a.stride = 1; a.pad = 0; a.K = 64;
-    a.M = (int)m_ll; a.relu = 1; a.tiles_n = 1; a.ksplit = 1; a.kchunk = 2; a.partial = nullptr; a.clamped = clamped;
+    a.M = (int)m_ll; a.relu = 1; a.tiles_n = 1; a.ksplit = 1; a.kchunk = 2; a.partial = nullptr; a.clamped = clamped; a.f32 = 0;
     u.c1 = a;
     u.c2 = a;
     u.c2.x = nullptr; u.c2.w = static_cast<const uint8_t*>(p2.w); u.c2.bias = p2.bias; u.c2.w_inv_scale = p2.w_inv_scale;

@@ -10,6 +10,8 @@ struct SplitConvParams {
     float w_inv_scale = 1.f;       // power of two; the accumulator is multiplied by it
     const float* bias = nullptr;   // [cout] or NULL
     int relu = 0;
+    bool f32 = false;              // float32 operands: w is the float32 packing of fd_conv.h ([cout_pad][K] floats,
+                                   // w_inv_scale 1), the input and the "split" output are plain float32 tensors
 };
 
 struct SplitConvOut {
@@ -56,8 +58,10 @@ int unit_proj_fused_forward(const SplitConvParams& conv1, const SplitConvParams&
 
 // float32 [rows][channels] -> split, optionally through relu(x * scale[c] + shift[c]).
 // (`clamped` in this and the following functions: the device counter described at SplitConvOut, may be NULL)
+// (f32 = true in this and the following functions: the output is the plain float32 tensor of the activated
+// values -- the operand format of the float32 convolutions -- instead of the split form)
 int to_split(const float* x, long long rows, int channels, const float* scale, const float* shift, void* y,
-             unsigned* clamped, hipStream_t stream);
+             unsigned* clamped, hipStream_t stream, bool f32 = false);
 
 int stage_input_split(const uint8_t* frames, int batch, int h, int w, const InputNorm& norm, void* y,
                       unsigned* clamped, hipStream_t stream);
@@ -74,6 +78,6 @@ int stem_pool_forward(const SplitConvParams& p, const void* staged_planar, int b
                       unsigned* clamped, hipStream_t stream);
 
 int maxpool_3x3s2_split(const float* x, int batch, int h, int w, int c, const float* scale, const float* shift,
-                        float* y32, void* ysplit, unsigned* clamped, hipStream_t stream);
+                        float* y32, void* ysplit, unsigned* clamped, hipStream_t stream, bool f32 = false);
 
 }  // namespace fd

@@ -295,7 +295,9 @@ __global__ __launch_bounds__(256, 2) void conv_split_kernel(SplitKArgs a) {
 // a tile twice as tall, one workgroup per CU; per multiply the larger tile moves 25 % fewer bytes
 // from L2 into LDS, which is what bounds the long-K layers (the 128 x 128 loop of the RPN 3x3
 // takes 976 us with the MFMAs removed and 1141 us with the LDS-DMA removed, 1476 us as it is).
-template <int BM, int BN, int NS, int WAVES = 4>
+// F32: the operands are float32 (a staged row = 32 floats) and the products run on the fp32 matrix
+// cores; loads, LDS image, pipeline and epilogue are the same code.
+template <int BM, int BN, int NS, int WAVES = 4, bool F32 = false>
 __global__ __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) void conv_split_glds_kernel(SplitKArgs a, unsigned x_bytes,
                                                                                       unsigned w_bytes) {
 #if defined(__HIP_DEVICE_COMPILE__)   // buffer-resource builtins exist in device code only; the host pass needs just the stub
@@ -438,7 +440,8 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) void conv_split_gld
 #define FD_STEP(CUR, KT)                                                                          \
     do {                                                                                          \
         if ((KT) + NS - 1 < nk) FD_ISSUE((KT) + NS - 1, ((CUR) + NS - 1) % NS);                   \
-        split_mma_step<2 * WROWS, BN>(sbase + (CUR) * STAGE * 4, a_off, b_off, acc);              \
+        if (F32) f32_mma_step<2 * WROWS, BN>(sbase + (CUR) * STAGE * 4, a_off, b_off, acc);       \
+        else split_mma_step<2 * WROWS, BN>(sbase + (CUR) * STAGE * 4, a_off, b_off, acc);         \
         FD_WAIT(min(NS - 2, nk - 2 - (KT)));                                                      \
         pipeline_barrier();                                                                       \
     } while (0)
@@ -474,16 +477,16 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) void conv_split_gld
 #endif
 }
 
-template <int BM, int BN, int NS, int WAVES = 4>
+template <int BM, int BN, int NS, int WAVES = 4, bool F32 = false>
 static int launch_split_glds(const SplitKArgs& a, size_t x_bytes, size_t w_bytes, hipStream_t stream) {
-    static const std::string name = std::string("conv_split_") + std::to_string(BM) + "x" + std::to_string(BN);
+    static const std::string name = std::string(F32 ? "conv_f32_" : "conv_split_") + std::to_string(BM) + "x" + std::to_string(BN);
     ProfScope scope(stream, name.c_str(), 2.0 * a.M * a.Cout * (double)a.K,
                     (double)a.H * a.W * (a.M / ((double)a.Ho * a.Wo)) * 4.0 * a.Cin + 4.0 * a.Cout * (double)a.K +
                         4.0 * a.M * a.Cout * ((a.res ? 1.0 : 0.0) + (a.y32 ? 1.0 : 0.0) + (a.ysplit ? 1.0 : 0.0)));
     SplitKArgs k = a;
     const int tiles_m = ceil_div(a.M, BM);
     k.tiles_n = ceil_div(a.Cout, BN);
-    hipLaunchKernelGGL((conv_split_glds_kernel<BM, BN, NS, WAVES>), dim3(tiles_m * k.tiles_n * k.ksplit),
+    hipLaunchKernelGGL((conv_split_glds_kernel<BM, BN, NS, WAVES, F32>), dim3(tiles_m * k.tiles_n * k.ksplit),
                        dim3(WAVES * 64), 0, stream, k, (unsigned)x_bytes, (unsigned)w_bytes);
     FD_LAUNCH_CHECK();
     return FD_OK;
@@ -502,7 +505,9 @@ static int launch_split_glds(const SplitKArgs& a, size_t x_bytes, size_t w_bytes
 // padding taps read zeros through the range check.
 enum { REG_PRE = 0, REG_STEM = 1 };
 
-template <int BM, int BN, int MODE>
+// F32 (REG_PRE only): float32 operands -- the activated values go to LDS as floats (one 16-byte chunk
+// per thread) and the products run on the fp32 matrix cores.
+template <int BM, int BN, int MODE, bool F32 = false>
 __global__ __launch_bounds__(256, 2) void conv_split_reg_kernel(SplitKArgs a, unsigned x_bytes, unsigned w_bytes) {
 #if defined(__HIP_DEVICE_COMPILE__)
     using T = SplitTile<BM, BN>;
@@ -545,7 +550,8 @@ __global__ __launch_bounds__(256, 2) void conv_split_reg_kernel(SplitKArgs a, un
         hi0[i] = ho * a.stride - a.pad;
         wi0[i] = wo * a.stride - a.pad;
         abase[i] = (unsigned)(((img * a.H + hi0[i]) * a.W + wi0[i]) * a.Cin * 4 + c4 * 16);
-        a_lds[i] = (unsigned)(row * 128 + (((c4 >> 1) ^ ((row >> 1) & 7)) * 16) + (c4 & 1) * 8);
+        a_lds[i] = F32 ? (unsigned)(row * 128 + ((c4 ^ ((row >> 1) & 7)) * 16))
+                       : (unsigned)(row * 128 + (((c4 >> 1) ^ ((row >> 1) & 7)) * 16) + (c4 & 1) * 8);
     }
     // weights: as in the direct-to-LDS kernel
     const int lrow = lane >> 3, lpos = lane & 7;
@@ -617,6 +623,16 @@ __global__ __launch_bounds__(256, 2) void conv_split_reg_kernel(SplitKArgs a, un
         char* sb_ = reinterpret_cast<char*>(smem) + (STG) * STAGE * 4;                            \
         _Pragma("unroll") for (int i = 0; i < RA; ++i) {                                          \
             f16x4 h_, l_;                                                                         \
+            if (F32) {                                                                            \
+                f32x4 v_;                                                                         \
+                _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                   \
+                    float t_ = ra[i][j] * psc[j] + psh[j];                                        \
+                    if (!((lok >> i) & 1u)) t_ = 0.f;                                             \
+                    v_[j] = fmaxf(t_, 0.f);                                                       \
+                }                                                                                 \
+                *reinterpret_cast<f32x4*>(sb_ + a_lds[i]) = v_;                                   \
+                continue;                                                                         \
+            }                                                                                     \
             if (MODE == REG_PRE) {                                                                \
                 _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                   \
                     float t_ = ra[i][j] * psc[j] + psh[j];                                        \
@@ -657,7 +673,8 @@ __global__ __launch_bounds__(256, 2) void conv_split_reg_kernel(SplitKArgs a, un
     do {                                                                                          \
         const bool more_ = (KT) + 1 < nk;                                                         \
         if (more_) FD_GLOAD((KT) + 1, (CUR) ^ 1);                                                 \
-        split_mma_step<BM, BN>(sbase + (CUR) * STAGE * 4, a_off, b_off, acc);                     \
+        if (F32) f32_mma_step<BM, BN>(sbase + (CUR) * STAGE * 4, a_off, b_off, acc);              \
+        else split_mma_step<BM, BN>(sbase + (CUR) * STAGE * 4, a_off, b_off, acc);                \
         if (more_) FD_LSTORE((CUR) ^ 1);                                                          \
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                          \
         __syncthreads();                                                                          \
@@ -676,7 +693,7 @@ __global__ __launch_bounds__(256, 2) void conv_split_reg_kernel(SplitKArgs a, un
 #undef FD_LSTORE
 #undef FD_GLOAD
 #undef FD_TAP
-    if (MODE == REG_PRE) split_report(a.clamped, bad);
+    if (MODE == REG_PRE && !F32) split_report(a.clamped, bad);
     if (a.ksplit > 1) {
         SplitKArgs e = a;
         e.y32 = a.partial + (size_t)ks * a.M * a.Cout;
@@ -688,10 +705,11 @@ __global__ __launch_bounds__(256, 2) void conv_split_reg_kernel(SplitKArgs a, un
 #endif
 }
 
-template <int BM, int BN, int MODE>
+template <int BM, int BN, int MODE, bool F32 = false>
 static int launch_split_reg(const SplitKArgs& a, size_t x_bytes, size_t w_bytes, hipStream_t stream) {
-    static const std::string name = std::string("conv_split_") + std::to_string(BM) + "x" + std::to_string(BN) +
-                                    (MODE == REG_STEM ? "_stem" : "_pre");
+    static_assert(!F32 || MODE == REG_PRE, "the float32 form exists for the BatchNorm-on-load kernel only");
+    static const std::string name = std::string(F32 ? "conv_f32_" : "conv_split_") + std::to_string(BM) + "x" +
+                                    std::to_string(BN) + (MODE == REG_STEM ? "_stem" : "_pre");
     const double taps = MODE == REG_STEM ? 147.0 : (double)a.K;
     const double cin_bytes = MODE == REG_STEM ? 16.0 : 4.0 * a.Cin;
     ProfScope scope(stream, name.c_str(), 2.0 * a.M * a.Cout * taps,
@@ -700,8 +718,8 @@ static int launch_split_reg(const SplitKArgs& a, size_t x_bytes, size_t w_bytes,
     SplitKArgs k = a;
     const int tiles_m = ceil_div(a.M, BM);
     k.tiles_n = ceil_div(a.Cout, BN);
-    hipLaunchKernelGGL((conv_split_reg_kernel<BM, BN, MODE>), dim3(tiles_m * k.tiles_n * k.ksplit), dim3(256), 0, stream,
-                       k, (unsigned)x_bytes, (unsigned)w_bytes);
+    hipLaunchKernelGGL((conv_split_reg_kernel<BM, BN, MODE, F32>), dim3(tiles_m * k.tiles_n * k.ksplit), dim3(256), 0,
+                       stream, k, (unsigned)x_bytes, (unsigned)w_bytes);
     FD_LAUNCH_CHECK();
     return FD_OK;
 }
@@ -765,6 +783,12 @@ __global__ __launch_bounds__(256) void split_k_finish_kernel(SplitKArgs a) {
                 v1[j] = fmaxf(v1[j] * s1[j] + t1[j], 0.f);
             }
         }
+        if (a.f32) {
+            float* ap = reinterpret_cast<float*>(a.ysplit) + off;
+            *reinterpret_cast<f32x4*>(ap) = v0;
+            *reinterpret_cast<f32x4*>(ap + 4) = v1;
+            return;
+        }
         f16x8 hi, lo;
         unsigned bad = 0;
         split8(v0, v1, hi, lo, bad);
@@ -821,7 +845,7 @@ static int split_conv_dispatch(const SplitConvParams& p, const void* x_split, co
     a.pre_scale = pre_scale; a.pre_shift = pre_shift;
     a.H = h; a.W = w; a.Cin = s.cin; a.Ho = ho; a.Wo = wo; a.Cout = s.cout; a.KW = s.kwp;
     a.stride = s.stride; a.pad = s.pad; a.K = s.k(); a.M = (int)m_ll; a.relu = p.relu; a.tiles_n = 0;
-    a.ksplit = 1; a.kchunk = a.K / SBK; a.partial = nullptr; a.clamped = out.clamped;
+    a.ksplit = 1; a.kchunk = a.K / SBK; a.partial = nullptr; a.clamped = out.clamped; a.f32 = p.f32 ? 1 : 0;
     FD_REQUIRE(!(stem && pre_scale), "split conv: the stem takes the staged image only");
     // the buffer-addressed kernels use 32-bit byte offsets below 2^31 into both tensors
     const size_t x_bytes = (size_t)batch * h * w * s.cin * 4, w_bytes = s.packed_floats() * 4;
@@ -832,6 +856,29 @@ static int split_conv_dispatch(const SplitConvParams& p, const void* x_split, co
     }
     const long long t128 = (long long)ceil_div(a.M, 128) * ceil_div(s.cout, 128);
     const long long t12864 = (long long)ceil_div(a.M, 128) * ceil_div(s.cout, 64);
+    if (p.f32) {
+        // float32 operands on the fp32 matrix cores: the same two kernel families (direct-to-LDS for
+        // activated inputs, BatchNorm-on-load through registers).  Measured on the layers of the 1080p
+        // network, 128 x 128 tiles with two workgroups per CU are as fast as the eight-wave 256-row tiles
+        // (the fp32 matrix pipe, not the path into LDS, is the limit), so only the four-wave shapes are used.
+        FD_REQUIRE(small && !stem, "float32 convolution: tensor beyond the 2^31-byte reach of the buffer-addressed kernels");
+        a.ksplit = choose_split_k(ho * wo, a.K / SBK, (long long)a.M * s.cout, out.splitk_ws_floats, &a.kchunk);
+        if (a.ksplit > 1) {
+            a.partial = out.splitk_ws;
+            if (pre_scale) FD_TRY((launch_split_reg<64, 64, REG_PRE, true>(a, x_bytes, w_bytes, stream)));
+            else if (a.M >= 1024 && s.cout >= 512) FD_TRY((launch_split_glds<128, 128, 2, 4, true>(a, x_bytes, w_bytes, stream)));
+            else FD_TRY((launch_split_glds<64, 64, 4, 4, true>(a, x_bytes, w_bytes, stream)));
+            return split_k_finish(a, stream);
+        }
+        if (pre_scale) {
+            if (s.cout > 64 && t128 >= 384) return launch_split_reg<128, 128, REG_PRE, true>(a, x_bytes, w_bytes, stream);
+            if (t12864 >= 384) return launch_split_reg<128, 64, REG_PRE, true>(a, x_bytes, w_bytes, stream);
+            return launch_split_reg<64, 64, REG_PRE, true>(a, x_bytes, w_bytes, stream);
+        }
+        if (s.cout > 64 && t128 >= 384) return launch_split_glds<128, 128, 2, 4, true>(a, x_bytes, w_bytes, stream);
+        if (t12864 >= 384) return launch_split_glds<128, 64, 3, 4, true>(a, x_bytes, w_bytes, stream);
+        return launch_split_glds<64, 64, 4, 4, true>(a, x_bytes, w_bytes, stream);
+    }
     if (small) {
         // ROI-head layers: split K whenever the workspace allows, whatever the batch size
         a.ksplit = choose_split_k(ho * wo, a.K / SBK, (long long)a.M * s.cout, out.splitk_ws_floats, &a.kchunk);
@@ -927,7 +974,7 @@ int pack_conv_weights_split(const float* w_oihw, int cin_w, const ConvShape& s, 
 // float32 [rows][C] -> split [rows][C], optionally through relu(x * scale[c] + shift[c])
 __global__ __launch_bounds__(256) void to_split_kernel(const float* __restrict__ x, long long rows, int C,
                                                       const float* __restrict__ scale, const float* __restrict__ shift,
-                                                      uint8_t* __restrict__ y, unsigned* __restrict__ clamped) {
+                                                      uint8_t* __restrict__ y, unsigned* __restrict__ clamped, int f32) {
     const long long t = (long long)blockIdx.x * 256 + threadIdx.x;     // one thread per 8 channels
     const int c8n = C / 8;
     if (t >= rows * c8n) return;
@@ -944,6 +991,12 @@ __global__ __launch_bounds__(256) void to_split_kernel(const float* __restrict__
             v1[j] = fmaxf(v1[j] * s1[j] + t1[j], 0.f);
         }
     }
+    if (f32) {
+        float* ap = reinterpret_cast<float*>(y) + r * C + c;
+        *reinterpret_cast<f32x4*>(ap) = v0;
+        *reinterpret_cast<f32x4*>(ap + 4) = v1;
+        return;
+    }
     f16x8 hi, lo;
     unsigned bad = 0;
     split8(v0, v1, hi, lo, bad);
@@ -954,12 +1007,12 @@ __global__ __launch_bounds__(256) void to_split_kernel(const float* __restrict__
 }
 
 int to_split(const float* x, long long rows, int channels, const float* scale, const float* shift, void* y,
-             unsigned* clamped, hipStream_t stream) {
+             unsigned* clamped, hipStream_t stream, bool f32) {
     FD_REQUIRE(x && y && channels % 32 == 0, "to_split: channels must be a multiple of 32");
     if (rows <= 0) return FD_OK;
     ProfScope scope(stream, "to_split", 0.0, 8.0 * (double)rows * channels);
     hipLaunchKernelGGL(to_split_kernel, dim3(ceil_div(rows * (channels / 8), 256)), dim3(256), 0, stream, x, rows,
-                       channels, scale, shift, static_cast<uint8_t*>(y), clamped);
+                       channels, scale, shift, static_cast<uint8_t*>(y), clamped, f32 ? 1 : 0);
     FD_LAUNCH_CHECK();
     return FD_OK;
 }
@@ -1048,7 +1101,8 @@ int stage_input_planar(const uint8_t* frames, int batch, int h, int w, const Inp
 __global__ __launch_bounds__(256) void maxpool_split_kernel(const float* __restrict__ x, int B, int H, int W, int C, int Ho,
                                                            int Wo, const float* __restrict__ scale,
                                                            const float* __restrict__ shift, float* __restrict__ y32,
-                                                           uint8_t* __restrict__ ysplit, unsigned* __restrict__ clamped) {
+                                                           uint8_t* __restrict__ ysplit, unsigned* __restrict__ clamped,
+                                                           int f32) {
     const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
     const int c8n = C / 8;
     if (t >= (long long)B * Ho * Wo * c8n) return;
@@ -1086,6 +1140,12 @@ __global__ __launch_bounds__(256) void maxpool_split_kernel(const float* __restr
                 m1[j] = fmaxf(m1[j] * s1[j] + t1[j], 0.f);
             }
         }
+        if (f32) {
+            float* ap = reinterpret_cast<float*>(ysplit) + pix * C + c;
+            *reinterpret_cast<f32x4*>(ap) = m0;
+            *reinterpret_cast<f32x4*>(ap + 4) = m1;
+            return;
+        }
         f16x8 hi, lo;
         unsigned bad = 0;
         split8(m0, m1, hi, lo, bad);
@@ -1097,14 +1157,14 @@ __global__ __launch_bounds__(256) void maxpool_split_kernel(const float* __restr
 }
 
 int maxpool_3x3s2_split(const float* x, int batch, int h, int w, int c, const float* scale, const float* shift,
-                        float* y32, void* ysplit, unsigned* clamped, hipStream_t stream) {
+                        float* y32, void* ysplit, unsigned* clamped, hipStream_t stream, bool f32) {
     FD_REQUIRE(x && (y32 || ysplit) && c % 32 == 0, "maxpool (split): bad arguments");
     const int ho = (h + 2 - 3) / 2 + 1, wo = (w + 2 - 3) / 2 + 1;
     const long long total = (long long)batch * ho * wo * (c / 8);
     ProfScope scope(stream, "maxpool_3x3s2", 0.0,
                     4.0 * c * ((double)batch * h * w + (double)batch * ho * wo * ((y32 ? 1 : 0) + (ysplit ? 1 : 0))));
     hipLaunchKernelGGL(maxpool_split_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, stream, x, batch, h, w, c, ho, wo,
-                       scale, shift, y32, static_cast<uint8_t*>(ysplit), clamped);
+                       scale, shift, y32, static_cast<uint8_t*>(ysplit), clamped, f32 ? 1 : 0);
     FD_LAUNCH_CHECK();
     return FD_OK;
 }

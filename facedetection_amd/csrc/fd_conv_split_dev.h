@@ -26,6 +26,8 @@ struct SplitKArgs {
     int ksplit, kchunk;
     float* partial;
     unsigned* clamped;       // device counter of values outside the fp16 range met while splitting (may be NULL)
+    int f32;                 // float32 operands: x, w and the "split" output are plain float32 tensors (same
+                             // 4 bytes per element, so the same addressing; 128-byte rows of 32 floats)
 };
 
 constexpr int SBK = 32;      // k per K-step
@@ -81,6 +83,34 @@ __device__ __forceinline__ void split_mma_step(const char* stage, const int (&a_
                 acc[mi][n0 + ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[mi], bl[ni], acc[mi][n0 + ni], 0, 0, 0);
                 acc[mi][n0 + ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[mi], bh[ni], acc[mi][n0 + ni], 0, 0, 0);
             }
+        __builtin_amdgcn_s_setprio(0);
+    }
+}
+
+// The same K-step with float32 operands (v_mfma_f32_16x16x4_f32): a staged row is 32 floats, chunk
+// part * 4 + (lane >> 4) of a row gives a lane k = 4 * chunk .. + 3, and MFMA t of a part multiplies
+// element t of both operands, i.e. the k set {4 * (part * 4 + g) + t : g = 0..3} -- the same
+// permutation of k for both operands.  Blocks are visited innermost so that consecutive MFMAs
+// write different accumulators.
+template <int BM, int BN>
+__device__ __forceinline__ void f32_mma_step(const char* stage, const int (&a_off)[2], const int (&b_off)[2],
+                                             f32x4 (&acc)[BM / 32][BN / 32]) {
+    constexpr int AM = BM / 32, AN = BN / 32;
+#pragma unroll
+    for (int part = 0; part < 2; ++part) {
+        f32x4 av[AM], bv[AN];
+#pragma unroll
+        for (int mi = 0; mi < AM; ++mi) av[mi] = *reinterpret_cast<const f32x4*>(stage + a_off[part] + mi * 2048);
+#pragma unroll
+        for (int ni = 0; ni < AN; ++ni) bv[ni] = *reinterpret_cast<const f32x4*>(stage + b_off[part] + ni * 2048);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int mi = 0; mi < AM; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < AN; ++ni)
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mi][t], bv[ni][t], acc[mi][ni], 0, 0, 0);
         __builtin_amdgcn_s_setprio(0);
     }
 }
@@ -228,11 +258,18 @@ __device__ __forceinline__ void split_epilogue16_rows(const SplitKArgs& a, float
                             v1[j] = fmaxf(v1[j] * ps1[j] + pt1[j], 0.f);
                         }
                     }
-                    f16x8 hi, lo;
-                    split8(v0, v1, hi, lo, bad);
-                    uint8_t* sp = a.ysplit + (size_t)row * a.Cout * 4 + split_offset(gcol);
-                    *reinterpret_cast<f16x8*>(sp) = hi;
-                    *reinterpret_cast<f16x8*>(sp + 64) = lo;
+                    if (a.f32) {
+                        // float32 operands: the activated tensor is a plain float32 tensor
+                        float* ap = reinterpret_cast<float*>(a.ysplit) + (size_t)row * a.Cout + gcol;
+                        *reinterpret_cast<f32x4*>(ap) = v0;
+                        *reinterpret_cast<f32x4*>(ap + 4) = v1;
+                    } else {
+                        f16x8 hi, lo;
+                        split8(v0, v1, hi, lo, bad);
+                        uint8_t* sp = a.ysplit + (size_t)row * a.Cout * 4 + split_offset(gcol);
+                        *reinterpret_cast<f16x8*>(sp) = hi;
+                        *reinterpret_cast<f16x8*>(sp + 64) = lo;
+                    }
                 }
             }
         }

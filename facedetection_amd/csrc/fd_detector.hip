@@ -22,7 +22,8 @@ constexpr int POOLED = 7;
 
 struct Unit {
     ConvParams conv1, conv2, conv3, sc;
-    SplitConvParams s_conv1, s_conv2, s_conv3, s_sc;
+    SplitConvParams s_conv1, s_conv2, s_conv3, s_sc;   // split (f16x3) operands
+    SplitConvParams f_conv1, f_conv2, f_conv3, f_sc;   // float32 operands on the same kernels
     const float *bn1_scale = nullptr, *bn1_shift = nullptr;   // the unit's input BatchNorm (device)
     bool has_sc = false;
 };
@@ -49,6 +50,7 @@ struct fd_detector {
     std::vector<fd::Unit> stage[4];
     fd::ConvParams rpn_conv, rpn_out;
     fd::SplitConvParams s_conv0, s_rpn_conv, s_rpn_out;
+    fd::SplitConvParams f_rpn_conv, f_rpn_out;
     int precision = FD_PRECISION_F16X3;
     const float *bn1_scale = nullptr, *bn1_shift = nullptr;
     const float *w_cls = nullptr, *b_cls = nullptr, *w_box = nullptr, *b_box = nullptr;
@@ -125,7 +127,8 @@ static int bn_fold(const ParamTable& t, const std::string& name, int ch, bool fi
 
 // Uploads OIHW weights, packs them for the GEMM (scaled per output channel when out_scale is given).
 static int make_conv(fd_detector* d, const float* w_host, int cin_w, ConvShape s, const std::vector<float>* out_scale,
-                     const std::vector<float>* bias, int relu, ConvParams* out, SplitConvParams* sout) {
+                     const std::vector<float>* bias, int relu, ConvParams* out, SplitConvParams* sout,
+                     SplitConvParams* fout = nullptr) {
     float *raw = nullptr, *scale_d = nullptr, *packed = nullptr, *bias_d = nullptr;
     const size_t nraw = (size_t)s.cout * cin_w * s.kh * s.kw;
     FD_HIP(hipMalloc((void**)&raw, nraw * sizeof(float)));
@@ -169,6 +172,14 @@ static int make_conv(fd_detector* d, const float* w_host, int cin_w, ConvShape s
     sout->w_inv_scale = 1.0f / wscale;
     sout->bias = bias_d;
     sout->relu = relu;
+    if (fout) {
+        fout->s = s;
+        fout->w = packed;
+        fout->w_inv_scale = 1.0f;
+        fout->bias = bias_d;
+        fout->relu = relu;
+        fout->f32 = true;
+    }
     return FD_OK;
 }
 
@@ -194,18 +205,18 @@ static int build_unit(fd_detector* d, const ParamTable& t, const std::string& na
     float *pre_s = nullptr, *pre_h = nullptr;
     FD_TRY(upload(d, s1.data(), s1.size(), &pre_s));
     FD_TRY(upload(d, h1.data(), h1.size(), &pre_h));
-    FD_TRY(make_conv(d, w1->data_host, cin, shape(cin, mid, 1, 1, 0), &s2, &h2, 1, &u->conv1, &u->s_conv1));
+    FD_TRY(make_conv(d, w1->data_host, cin, shape(cin, mid, 1, 1, 0), &s2, &h2, 1, &u->conv1, &u->s_conv1, &u->f_conv1));
     u->conv1.pre_scale = pre_s;
     u->conv1.pre_shift = pre_h;
     u->bn1_scale = pre_s;
     u->bn1_shift = pre_h;
-    FD_TRY(make_conv(d, w2->data_host, mid, shape(mid, mid, 3, stride, 1), &s3, &h3, 1, &u->conv2, &u->s_conv2));
-    FD_TRY(make_conv(d, w3->data_host, mid, shape(mid, cout, 1, 1, 0), nullptr, nullptr, 0, &u->conv3, &u->s_conv3));
+    FD_TRY(make_conv(d, w2->data_host, mid, shape(mid, mid, 3, stride, 1), &s3, &h3, 1, &u->conv2, &u->s_conv2, &u->f_conv2));
+    FD_TRY(make_conv(d, w3->data_host, mid, shape(mid, cout, 1, 1, 0), nullptr, nullptr, 0, &u->conv3, &u->s_conv3, &u->f_conv3));
     u->has_sc = !dim_match;
     if (u->has_sc) {
         const fd_param* ws = t.get(name + "_sc_weight", (int64_t)cout * cin);
         if (!ws) return FD_ERR_PARAM;
-        FD_TRY(make_conv(d, ws->data_host, cin, shape(cin, cout, 1, stride, 0), nullptr, nullptr, 0, &u->sc, &u->s_sc));
+        FD_TRY(make_conv(d, ws->data_host, cin, shape(cin, cout, 1, stride, 0), nullptr, nullptr, 0, &u->sc, &u->s_sc, &u->f_sc));
         u->sc.pre_scale = pre_s;
         u->sc.pre_shift = pre_h;
     }
@@ -241,7 +252,7 @@ static int build(fd_detector* d, const ParamTable& t) {
         const fd_param* b = t.get("rpn_conv_3x3_bias", 512);
         if (!w || !b) return FD_ERR_PARAM;
         std::vector<float> bias(b->data_host, b->data_host + 512);
-        FD_TRY(make_conv(d, w->data_host, 1024, shape(1024, 512, 3, 1, 1), nullptr, &bias, 1, &d->rpn_conv, &d->s_rpn_conv));
+        FD_TRY(make_conv(d, w->data_host, 1024, shape(1024, 512, 3, 1, 1), nullptr, &bias, 1, &d->rpn_conv, &d->s_rpn_conv, &d->f_rpn_conv));
         const int A = d->prop.num_ratios * d->prop.num_scales;
         const fd_param* wc = t.get("rpn_cls_score_weight", 2ll * A * 512);
         const fd_param* bc = t.get("rpn_cls_score_bias", 2 * A);
@@ -253,7 +264,7 @@ static int build(fd_detector* d, const ParamTable& t) {
         memcpy(wcat.data() + 2ull * A * 512, wb->data_host, sizeof(float) * 4 * A * 512);
         memcpy(bcat.data(), bc->data_host, sizeof(float) * 2 * A);
         memcpy(bcat.data() + 2 * A, bb->data_host, sizeof(float) * 4 * A);
-        FD_TRY(make_conv(d, wcat.data(), 512, shape(512, 6 * A, 1, 1, 0), nullptr, &bcat, 0, &d->rpn_out, &d->s_rpn_out));
+        FD_TRY(make_conv(d, wcat.data(), 512, shape(512, 6 * A, 1, 1, 0), nullptr, &bcat, 0, &d->rpn_out, &d->s_rpn_out, &d->f_rpn_out));
     }
     // head: bn1 + relu + global average, then the two FullyConnected layers
     FD_TRY(bn_fold(t, "bn1", FILTERS[4], false, sc, sh));
@@ -282,6 +293,7 @@ static int build(fd_detector* d, const ParamTable& t) {
 struct Plan {
     fd_detector* d;
     bool dry;
+    bool f32 = false;          // float32 operands (FD_PRECISION_F32) on the graph of run_graph_split
     size_t need[NB_COUNT];
     hipStream_t stream;
 
@@ -452,8 +464,12 @@ static int run_graph(Plan& pl, const uint8_t* frames, int B, int H, int W, float
 static int run_unit_split(Plan& pl, const Unit& u, const char* name, const void* act, const float* xraw, int n, int h,
                           int w, float* y32, void* ysplit, const float* next_scale, const float* next_shift,
                           int* ho_out, int* wo_out) {
-    const int mid = u.s_conv1.s.cout, cout = u.s_conv3.s.cout;
-    const int ho = u.s_conv2.s.out_h(h), wo = u.s_conv2.s.out_w(w);
+    const SplitConvParams& c1 = pl.f32 ? u.f_conv1 : u.s_conv1;
+    const SplitConvParams& c2 = pl.f32 ? u.f_conv2 : u.s_conv2;
+    const SplitConvParams& c3 = pl.f32 ? u.f_conv3 : u.s_conv3;
+    const SplitConvParams& csc = pl.f32 ? u.f_sc : u.s_sc;
+    const int mid = c1.s.cout, cout = c3.s.cout;
+    const int ho = c2.s.out_h(h), wo = c2.s.out_w(w);
     float* t1 = pl.buf(NB_T1, (size_t)n * h * w * mid);
     float* t2 = pl.buf(NB_T2, (size_t)n * ho * wo * mid);
     const float* res = xraw;
@@ -461,14 +477,14 @@ static int run_unit_split(Plan& pl, const Unit& u, const char* name, const void*
     // accumulated together, so neither the shortcut tensor nor t1/t2 exist
     bool whole_proj = false;
     if (u.has_sc && !pl.dry && (!pl.d->layerwise() || (pl.d->fuse_units & 4)) && (pl.d->fuse_units & 2) && y32 && !ysplit)
-        FD_TRY(unit_proj_fused_forward(u.s_conv1, u.s_conv2, u.s_conv3, u.s_sc, act, n, h, w, y32, pl.d->clamped,
+        FD_TRY(unit_proj_fused_forward(c1, c2, c3, csc, act, n, h, w, y32, pl.d->clamped,
                                        pl.stream, &whole_proj));
     if (u.has_sc) {
         float* s = pl.buf(NB_SC, (size_t)n * ho * wo * cout);
         if (!pl.dry && !whole_proj) {
             SplitConvOut o = pl.out();
             o.y32 = s;
-            FD_TRY(split_conv_forward(u.s_sc, act, n, h, w, nullptr, o, pl.stream));
+            FD_TRY(split_conv_forward(csc, act, n, h, w, nullptr, o, pl.stream));
         }
         res = s;
     }
@@ -484,21 +500,21 @@ static int run_unit_split(Plan& pl, const Unit& u, const char* name, const void*
         // input and output goes to HBM); the intermediate tensors exist only for inspection
         bool whole = false;
         if (!u.has_sc && (!pl.d->layerwise() || (pl.d->fuse_units & 4)) && (pl.d->fuse_units & 1))
-            FD_TRY(unit_fused_forward(u.s_conv1, u.s_conv2, u.s_conv3, xraw, u.bn1_scale, u.bn1_shift, n, h, w, o3,
+            FD_TRY(unit_fused_forward(c1, c2, c3, xraw, u.bn1_scale, u.bn1_shift, n, h, w, o3,
                                       pl.stream, &whole));
         if (!whole) {
             if (u.has_sc) {
-                FD_TRY(split_conv_forward(u.s_conv1, act, n, h, w, nullptr, o1, pl.stream));
+                FD_TRY(split_conv_forward(c1, act, n, h, w, nullptr, o1, pl.stream));
             } else {
-                FD_TRY(split_conv_forward_f32(u.s_conv1, xraw, u.bn1_scale, u.bn1_shift, n, h, w, nullptr, o1,
+                FD_TRY(split_conv_forward_f32(c1, xraw, u.bn1_scale, u.bn1_shift, n, h, w, nullptr, o1,
                                               pl.stream));
             }
             bool fused = false;
             if (!pl.d->layerwise())
-                FD_TRY(conv_tail_fused_forward(u.s_conv2, u.s_conv3, t1, n, h, w, res, o3, pl.stream, &fused));
+                FD_TRY(conv_tail_fused_forward(c2, c3, t1, n, h, w, res, o3, pl.stream, &fused));
             if (!fused) {
-                FD_TRY(split_conv_forward(u.s_conv2, t1, n, h, w, nullptr, o2, pl.stream));
-                FD_TRY(split_conv_forward(u.s_conv3, t2, n, ho, wo, res, o3, pl.stream));
+                FD_TRY(split_conv_forward(c2, t1, n, h, w, nullptr, o2, pl.stream));
+                FD_TRY(split_conv_forward(c3, t2, n, ho, wo, res, o3, pl.stream));
             }
         }
     }
@@ -520,18 +536,25 @@ static int run_graph_split(Plan& pl, const uint8_t* frames, int B, int H, int W,
     // kept for inspection the two-kernel form is used instead, because only it materialises the
     // convolution output.
     const size_t planar_floats = (size_t)B * H * staged_planar_width(W) * 4;
-    const bool fused_stem = !layerwise && planar_floats * 4 < (1ull << 31);
+    const bool f32 = pl.f32;                 // float32 operands: same graph, "split" tensors are plain float32
+    const bool fused_stem = !layerwise && !f32 && planar_floats * 4 < (1ull << 31);
     float* staged = pl.buf(NB_STAGED, fused_stem ? planar_floats : (size_t)B * H * W * 4);
     if (!pl.dry) {
         FD_HIP(hipMemsetAsync(d->clamped, 0, sizeof(unsigned), pl.stream));
-        if (fused_stem) FD_TRY(stage_input_planar(frames, B, H, W, d->norm, staged, d->clamped, pl.stream));
+        if (f32) FD_TRY(stage_input(frames, B, H, W, d->norm, staged, pl.stream));
+        else if (fused_stem) FD_TRY(stage_input_planar(frames, B, H, W, d->norm, staged, d->clamped, pl.stream));
         else FD_TRY(stage_input_split(frames, B, H, W, d->norm, staged, d->clamped, pl.stream));
     }
     float* c0 = fused_stem ? nullptr : pl.buf(NB_CONV0, (size_t)B * h1 * w1 * FILTERS[0]);
     if (!pl.dry && !fused_stem) {
-        SplitConvOut o = pl.out();
-        o.y32 = c0;
-        FD_TRY(split_conv_forward(d->s_conv0, staged, B, H, W, nullptr, o, pl.stream));
+        if (f32) {
+            // the 7x7 stem on the float32 staged image: the register-staged fp32 kernel
+            FD_TRY(conv_forward(d->conv0, staged, B, H, W, nullptr, c0, pl.stream));
+        } else {
+            SplitConvOut o = pl.out();
+            o.y32 = c0;
+            FD_TRY(split_conv_forward(d->s_conv0, staged, B, H, W, nullptr, o, pl.stream));
+        }
     }
     if (!fused_stem) pl.tap("conv0", c0, B, h1, w1, FILTERS[0]);
     int h = (h1 + 2 - 3) / 2 + 1, w = (w1 + 2 - 3) / 2 + 1;
@@ -554,7 +577,7 @@ static int run_graph_split(Plan& pl, const uint8_t* frames, int B, int H, int W,
         else
             FD_TRY(maxpool_3x3s2_split(c0, B, h1, w1, FILTERS[0], d->stage[0][0].bn1_scale,
                                        d->stage[0][0].bn1_shift, layerwise ? xbuf[0] : nullptr, abuf[0], d->clamped,
-                                       pl.stream));
+                                       pl.stream, f32));
     }
     if (layerwise && !fused_stem) pl.tap("pool0", xbuf[0], B, h, w, FILTERS[0]);
     int cur = 0;
@@ -569,7 +592,8 @@ static int run_graph_split(Plan& pl, const uint8_t* frames, int B, int H, int W,
             const bool want32 = last || keep || (next && !next->has_sc);
             float* y32 = want32 ? xbuf[cur ^ 1] : nullptr;
             // the split form is for a projection-shortcut successor and, after the last unit, the RPN
-            const bool want_split = last || (next && next->has_sc);
+            // (with float32 operands the RPN reads the raw feature map itself)
+            const bool want_split = (last && !f32) || (next && next->has_sc);
             FD_TRY(run_unit_split(pl, d->stage[s][u], name, abuf[cur], d->stage[s][u].has_sc ? nullptr : xraw, B, h, w,
                                   y32, want_split ? abuf[cur ^ 1] : nullptr, next ? next->bn1_scale : nullptr,
                                   next ? next->bn1_shift : nullptr, &h, &w));
@@ -577,7 +601,7 @@ static int run_graph_split(Plan& pl, const uint8_t* frames, int B, int H, int W,
             cur ^= 1;
         }
     const float* feat = xbuf[cur];
-    const void* feat_split = abuf[cur];    // split of the raw feature map (no BatchNorm): the RPN's input
+    const void* feat_split = f32 ? (const void*)xbuf[cur] : (const void*)abuf[cur];   // the RPN's input: the raw map (split form: no BatchNorm)
     pl.tap("feat", feat, B, h, w, FILTERS[3]);
     const int fh = h, fw = w;
     const int A = d->prop.num_ratios * d->prop.num_scales;
@@ -587,8 +611,8 @@ static int run_graph_split(Plan& pl, const uint8_t* frames, int B, int H, int W,
         SplitConvOut o1 = pl.out(), o2 = pl.out();
         o1.ysplit = hid;
         o2.y32 = rout;
-        FD_TRY(split_conv_forward(d->s_rpn_conv, feat_split, B, fh, fw, nullptr, o1, pl.stream));
-        FD_TRY(split_conv_forward(d->s_rpn_out, hid, B, fh, fw, nullptr, o2, pl.stream));
+        FD_TRY(split_conv_forward(f32 ? d->f_rpn_conv : d->s_rpn_conv, feat_split, B, fh, fw, nullptr, o1, pl.stream));
+        FD_TRY(split_conv_forward(f32 ? d->f_rpn_out : d->s_rpn_out, hid, B, fh, fw, nullptr, o2, pl.stream));
     }
     pl.tap("rpn_out", rout, B, fh, fw, 6 * A);
     float* rois = pl.buf(NB_ROIS, (size_t)B * R * 5);
@@ -618,11 +642,11 @@ static int run_graph_split(Plan& pl, const uint8_t* frames, int B, int H, int W,
         if (layerwise) {
             FD_TRY(roipool_nhwc(feat, B, FILTERS[3], fh, fw, rois, N, POOLED, POOLED, 1.0f / 16.0f, pooled, pl.stream));
             FD_TRY(to_split(pooled, (long long)N * POOLED * POOLED, FILTERS[3], d->stage[3][0].bn1_scale,
-                            d->stage[3][0].bn1_shift, a4buf[0], d->clamped, pl.stream));
+                            d->stage[3][0].bn1_shift, a4buf[0], d->clamped, pl.stream, f32));
         } else {
             FD_TRY(roipool_nhwc_split(feat, B, FILTERS[3], fh, fw, rois, N, POOLED, POOLED, 1.0f / 16.0f,
                                       d->stage[3][0].bn1_scale, d->stage[3][0].bn1_shift, a4buf[0], d->clamped,
-                                      pl.stream));
+                                      pl.stream, f32));
         }
     }
     if (layerwise) pl.tap("pooled", pooled, N, POOLED, POOLED, FILTERS[3]);
@@ -669,7 +693,11 @@ static int forward(fd_detector* d, const uint8_t* frames, int B, int H, int W, f
     Plan pl;
     pl.d = d; pl.stream = stream; pl.dry = true;
     memset(pl.need, 0, sizeof(pl.need));
-    const bool split = d->precision == FD_PRECISION_F16X3;
+    // Both precisions run the graph of run_graph_split; FD_F32_LAYERWISE=1 selects the older float32 pass
+    // that launches every layer with the register-staged fp32 kernel (comparisons only).
+    static const bool legacy_f32 = getenv("FD_F32_LAYERWISE") && atoi(getenv("FD_F32_LAYERWISE")) != 0;
+    pl.f32 = d->precision == FD_PRECISION_F32;
+    const bool split = !(pl.f32 && legacy_f32);
     FD_TRY((split ? run_graph_split : run_graph)(pl, frames, B, H, W, im_scale, nullptr, nullptr, nullptr));
     for (int i = 0; i < NB_COUNT; ++i) {
         Buf& b = d->net[i];
