@@ -13,7 +13,9 @@
 // floating-point contraction off.
 #include "fd_common.h"
 
+#include <algorithm>
 #include <cmath>
+#include <cstdlib>
 
 #pragma clang fp contract(off)
 
@@ -64,6 +66,132 @@ __global__ __launch_bounds__(256) void resize_linear_u8_kernel(const uint8_t* __
         const int h1 = r1[tx.s0 * c + k] * tx.w0 + r1[tx.s1 * c + k] * tx.w1;
         o[o0 + os * k] = (uint8_t)((((ty.w0 * (h0 >> 4)) >> 16) + ((ty.w1 * (h1 >> 4)) >> 16) + 2) >> 2);
     }
+}
+
+// ---------------------------------------------------------------------------------
+// The same resize for 3-channel frames with the source staged through LDS.  A workgroup owns a
+// tile of RZ_TY x RZ_TX destination pixels.  The source rectangle the tile's taps touch (about
+// RZ_TY / fy + 2 rows of RZ_TX / fx + 2 pixels) is read with 16-byte buffer loads -- whole aligned
+// chunks of every source row, consecutive lanes on consecutive chunks, so each row segment is one
+// coalesced burst and every source byte is fetched once per tile instead of once per tap and channel
+// with single-byte loads -- into LDS rows of `pitch` bytes; chunks past the end of the image return
+// zero through the buffer's range check.  The column and row taps of the tile are computed once
+// (one thread each) into LDS tables.  Then a thread produces 4 neighbouring destination pixels:
+// per pixel and source row three aligned LDS dwords and two byte-align operations give the 6 bytes of
+// the two tap pixels; the 12 output bytes leave as one 12-byte store (consecutive lanes write
+// consecutive addresses).  Arithmetic is that of resize_linear_u8_kernel, bit for bit.
+constexpr int RZ_TX = 128, RZ_TY = 8;
+
+template <bool AREA2, bool REVERSE>
+__global__ __launch_bounds__(256) void resize3_lds_kernel(const uint8_t* __restrict__ src, int sh, int sw, double scale_x,
+                                                         double scale_y, uint8_t* __restrict__ dst, int dh, int dw,
+                                                         int pitch, int max_rows) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    extern __shared__ __attribute__((aligned(16))) uint8_t rz_lds[];
+    int2* coltab = reinterpret_cast<int2*>(rz_lds + (size_t)max_rows * pitch);   // (first tap column, w0 | w1 << 16)
+    int4* rowtab = reinterpret_cast<int4*>(coltab + RZ_TX);                       // (tap rows, b0 << 16, b1 << 16)
+    const int tid = threadIdx.x, b = blockIdx.z;
+    const int dy0 = blockIdx.y * RZ_TY, dx0 = blockIdx.x * RZ_TX;
+    const int ny = min(RZ_TY, dh - dy0), nx = min(RZ_TX, dw - dx0);
+    // one tap per thread: columns of the tile, then its rows
+    if (tid < nx) {
+        if (AREA2) {
+            coltab[tid] = make_int2(2 * (dx0 + tid), 0);
+        } else {
+            const Tap2 t = linear_tap(dx0 + tid, scale_x, sw);
+            coltab[tid] = make_int2(t.s0, t.w0 | (t.w1 << 16));
+        }
+    } else if (tid >= RZ_TX && tid - RZ_TX < ny) {
+        const int r = tid - RZ_TX;
+        if (AREA2) {
+            rowtab[r] = make_int4(2 * (dy0 + r), 2 * (dy0 + r) + 1, 0, 0);
+        } else {
+            const Tap2 t = linear_tap(dy0 + r, scale_y, sh);
+            rowtab[r] = make_int4(t.s0, t.s1, t.w0 << 16, t.w1 << 16);
+        }
+    }
+    __syncthreads();
+    // taps are monotonic: the tile's source rectangle starts at the first column / row tap
+    const int c_lo = coltab[0].x, r_lo = rowtab[0].x;
+    const int nrows = min(rowtab[ny - 1].y - r_lo + 1, max_rows);
+    // the image as a buffer whose base is 16-byte aligned (the bytes before the image inside its first
+    // chunk belong to the same allocation)
+    const uint8_t* img = src + (size_t)b * sh * sw * 3;
+    const unsigned mis = (unsigned)(reinterpret_cast<uintptr_t>(img) & 15u);
+    // The range ends at the end of the image's last 16-byte chunk: a 16-byte load is dropped as a whole
+    // when it crosses the end of the range, and the bytes up to the chunk boundary lie in the same
+    // allocation granule as the image's last byte.
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(img - mis), 0, (unsigned)(((size_t)sh * sw * 3 + mis + 15) & ~(size_t)15), 0x00020000);
+    const int cpr = pitch >> 4;                       // 16-byte chunks per staged row
+    const unsigned origin = mis + (unsigned)(r_lo * sw + c_lo) * 3u;     // byte offset of (r_lo, c_lo) from the buffer base
+    const unsigned row_bytes = (unsigned)sw * 3u;
+    typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+    for (int i = tid; i < nrows * cpr; i += 256) {
+        const int r = i / cpr, ch = i - r * cpr;
+        const unsigned start = origin + (unsigned)r * row_bytes;
+        const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(rs, (start & ~15u) + (unsigned)ch * 16u, 0, 0);
+        *reinterpret_cast<u32x4_t*>(rz_lds + (size_t)r * pitch + ch * 16) = v;
+    }
+    __syncthreads();
+    constexpr int GX = RZ_TX / 4;
+    for (int item = tid; item < ny * GX; item += 256) {
+        const int ry = item / GX, gx = (item - ry * GX) * 4;
+        if (gx >= nx) continue;
+        const int4 rt = rowtab[ry];
+        const int r0 = rt.x - r_lo, r1 = rt.y - r_lo;
+        // byte position of source column c_lo inside each of the two staged rows (their alignment differs)
+        const unsigned base0 = (unsigned)r0 * (unsigned)pitch + ((origin + (unsigned)r0 * row_bytes) & 15u);
+        const unsigned base1 = (unsigned)r1 * (unsigned)pitch + ((origin + (unsigned)r1 * row_bytes) & 15u);
+        unsigned vout[12];
+#pragma unroll
+        for (int px = 0; px < 4; ++px) {
+            const int2 ct = coltab[min(gx + px, nx - 1)];
+            const unsigned coff = (unsigned)(ct.x - c_lo) * 3u;
+            unsigned lo[2], hi[2];                     // bytes 0..3 and 4..7 from the first tap pixel on, per row
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                const unsigned a = (r ? base1 : base0) + coff;
+                const unsigned* q = reinterpret_cast<const unsigned*>(rz_lds + (a & ~3u));
+                const unsigned d0 = q[0], d1 = q[1], d2 = q[2];
+                lo[r] = __builtin_amdgcn_alignbyte(d1, d0, a & 3u);
+                hi[r] = __builtin_amdgcn_alignbyte(d2, d1, a & 3u);
+            }
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                // (byte k) | (byte k + 3) << 16: channel k of the two tap pixels as a pair of 16-bit values
+                const unsigned sel = 0x0c000c00u | (unsigned)k | ((unsigned)(k + 3) << 16);
+                const unsigned p0 = __builtin_amdgcn_perm(hi[0], lo[0], sel);
+                const unsigned p1 = __builtin_amdgcn_perm(hi[1], lo[1], sel);
+                unsigned v;
+                if (AREA2) {
+                    v = ((p0 & 0xffffu) + (p0 >> 16) + (p1 & 0xffffu) + (p1 >> 16) + 2u) >> 2;
+                } else {
+                    const unsigned w0 = (unsigned)ct.y & 0xffffu, w1 = (unsigned)ct.y >> 16;
+                    const unsigned h0 = (p0 & 0xffffu) * w0 + (p0 >> 16) * w1;
+                    const unsigned h1 = (p1 & 0xffffu) * w0 + (p1 >> 16) * w1;
+                    // (b * (h >> 4)) >> 16 with b < 2^12, h >> 4 < 2^15: the high word of (b << 16) * (h >> 4)
+                    v = (__umulhi((unsigned)rt.z, h0 >> 4) + __umulhi((unsigned)rt.w, h1 >> 4) + 2u) >> 2;
+                }
+                vout[px * 3 + (REVERSE ? 2 - k : k)] = v;
+            }
+        }
+        uint8_t* o = dst + (((size_t)b * dh + dy0 + ry) * dw + dx0 + gx) * 3;
+        if (gx + 4 <= nx && (reinterpret_cast<uintptr_t>(o) & 3u) == 0) {
+            typedef unsigned u32x3_t __attribute__((ext_vector_type(3)));
+            u32x3_t w;
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+                w[j] = vout[4 * j] | (vout[4 * j + 1] << 8) | (vout[4 * j + 2] << 16) | (vout[4 * j + 3] << 24);
+            *reinterpret_cast<u32x3_t*>(o) = w;
+        } else {
+            const int nb = 3 * min(4, nx - gx);
+#pragma unroll
+            for (int j = 0; j < 12; ++j)
+                if (j < nb) o[j] = (uint8_t)vout[j];
+        }
+    }
+#endif
 }
 
 // ---------------------------------------------------------------------------------
@@ -177,6 +305,27 @@ int fd_resize_cvt_u8(fd_ctx* ctx, const uint8_t* src, int batch, int src_h, int 
     const int area2 = (scale_x == 2.0 && scale_y == 2.0 && src_w % 2 == 0 && src_h % 2 == 0) ? 1 : 0;
     fd::ProfScope scope(fd::as_stream(stream), "resize_linear_u8", 0.0,
                         (double)batch * channels * ((double)src_h * src_w + (double)dst_h * dst_w));
+    // 3-channel frames take the LDS-staged kernel whenever a tile's source rectangle fits in LDS (any
+    // scale from enlargements down to about 1/7); the per-pixel kernel is the general fallback.
+    static const bool allow_lds = !(getenv("FD_RESIZE_LDS") && atoi(getenv("FD_RESIZE_LDS")) == 0);
+    if (channels == 3 && allow_lds && (size_t)src_h * src_w * 3 < (1ull << 31) && batch <= 65535) {
+        const int max_rows = std::min(src_h, (int)std::ceil(fd::RZ_TY * scale_y) + 3);
+        const int max_cols = std::min(src_w, (int)std::ceil(fd::RZ_TX * scale_x) + 3);
+        const int pitch = ((max_cols * 3 + 15 + 8) + 15) / 16 * 16;     // worst lead + the taps' 8-byte window, in whole chunks
+        const size_t smem = (size_t)max_rows * pitch + fd::RZ_TX * sizeof(int2) + fd::RZ_TY * sizeof(int4);
+        if (smem <= 64 * 1024) {
+            dim3 grid(fd::ceil_div(dst_w, fd::RZ_TX), fd::ceil_div(dst_h, fd::RZ_TY), batch);
+            const hipStream_t st = fd::as_stream(stream);
+#define FD_RZ(A2, REV)                                                                                          \
+    hipLaunchKernelGGL((fd::resize3_lds_kernel<A2, REV>), grid, dim3(256), smem, st, src, src_h, src_w, scale_x, \
+                       scale_y, dst, dst_h, dst_w, pitch, max_rows)
+            if (area2) { if (reverse_channels) FD_RZ(true, true); else FD_RZ(true, false); }
+            else { if (reverse_channels) FD_RZ(false, true); else FD_RZ(false, false); }
+#undef FD_RZ
+            FD_LAUNCH_CHECK();
+            return FD_OK;
+        }
+    }
     dim3 grid(fd::ceil_div(dst_w, 64), fd::ceil_div(dst_h, 4), batch);
     hipLaunchKernelGGL(fd::resize_linear_u8_kernel, grid, dim3(256), 0, fd::as_stream(stream), src, src_h, src_w,
                        channels, scale_x, scale_y, dst, dst_h, dst_w, area2, reverse_channels ? 1 : 0);

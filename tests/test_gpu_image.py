@@ -42,6 +42,45 @@ def test_resize_arbitrary_factors(fx, fy):
     np.testing.assert_array_equal(ops.resize_bilinear(img, fx, fy), orz.resize_linear_u8(img, fx, fy))
 
 
+@pytest.mark.parametrize("shape,fx,fy", [((2160, 3840, 3), 1000.0 / 3840, 1000.0 / 3840),   # 4K -> 562 x 1000
+                                         ((1080, 1920, 3), 0.5, 0.5),                          # exact 2x: 2x2 average
+                                         ((217, 333, 3), 0.77, 0.41),                          # rows of 256 and 769 bytes: unaligned everywhere
+                                         ((130, 1203, 3), 0.2, 1.0),                           # strong horizontal reduction
+                                         ((97, 131, 3), 3.1, 2.3)])                            # enlargement
+def test_resize_lds_kernel_shapes(shape, fx, fy):
+    """Sizes chosen for the LDS-staged 3-channel kernel: tiles cut by the image edge, source rows
+    whose 16-byte alignment differs from row to row, destination rows that are not a multiple of
+    4 bytes, reductions and enlargements."""
+    from facedetection_amd import ops
+    rng = np.random.default_rng(shape[0])
+    img = rng.integers(0, 256, shape, dtype=np.uint8)
+    np.testing.assert_array_equal(ops.resize_bilinear(img, fx, fy), orz.resize_linear_u8(img, fx, fy))
+
+
+def test_resize_of_a_batch_slice_with_channel_swap():
+    """A batch that starts at an address that is not 16-byte aligned (a slice of a larger tensor
+    offset by one row of an odd-sized image), with the BGR -> RGB swap of the command-line loop."""
+    import ctypes as C
+
+    import torch
+    from facedetection_amd import _lib, runtime
+    rng = np.random.default_rng(8)
+    frames = rng.integers(0, 256, (4, 101, 203, 3), dtype=np.uint8)
+    dev = torch.from_numpy(frames).cuda()
+    part = dev[1:]                                             # 101 * 203 * 3 = 61509 bytes in: odd address
+    assert part.data_ptr() % 16 != 0
+    fx = fy = 0.6
+    dh, dw = C.c_int32(0), C.c_int32(0)
+    L = _lib.lib()
+    _lib.check(L.fd_resize_dims(101, 203, fx, fy, C.byref(dh), C.byref(dw)))
+    out = torch.empty((3, dh.value, dw.value, 3), dtype=torch.uint8, device="cuda")
+    _lib.check(L.fd_resize_cvt_u8(runtime.context(0).handle, runtime.ptr(part), 3, 101, 203, 3, fx, fy, 1, runtime.ptr(out),
+                                  dh.value, dw.value, runtime.stream_ptr(0)))
+    got = out.cpu().numpy()
+    for b in range(3):
+        np.testing.assert_array_equal(got[b], orz.resize_linear_u8(frames[1 + b], fx, fy)[:, :, ::-1])
+
+
 def test_resize_batch_and_gray():
     from facedetection_amd import ops
     rng = np.random.default_rng(6)

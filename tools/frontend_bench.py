@@ -40,8 +40,18 @@ def main():
     t = timed(lambda: ops.resize_bilinear(frames, scale, scale), 10)
     small = ops.resize_bilinear(frames, scale, scale)
     moved = frames.numel() + small.numel()
+    # the kernel's own duration (HIP events around the launch): the host loop above also pays for
+    # the allocation of the output and the launch itself, a good part of a ~50 us kernel
+    from facedetection_amd import _lib, profiling
+    profiling.begin()
+    for _ in range(20):
+        ops.resize_bilinear(frames, scale, scale)
+    row = [r for r in profiling.end() if r["kernel"] == "resize_linear_u8"][0]
+    tk = row["ms"] * 1e-3 / row["launches"]
     out["resize_1080p_to_%dx%d" % (small.shape[1], small.shape[2])] = {
-        "frames_per_s": round(n / t, 1), "GB_per_s": round(moved / t / 1e9, 1)}
+        "frames": n, "frames_per_s": round(n / t, 1), "GB_per_s": round(moved / t / 1e9, 1),
+        "kernel_us": round(tk * 1e6, 2), "kernel_GB_per_s": round(moved / tk / 1e9, 1),
+        "kernel_frac_of_8TBs": round(moved / tk / 8e12, 3), "library_build": _lib.lib().fd_build_id().decode()}
     # crop hand-off: 16 boxes per frame -> 112x112 tiles
     rng = np.random.default_rng(0)
     boxes = np.zeros((16, 5), dtype=np.float64)
