@@ -70,53 +70,56 @@ __global__ __launch_bounds__(256) void resize_linear_u8_kernel(const uint8_t* __
 
 // ---------------------------------------------------------------------------------
 // The same resize for 3-channel frames with the source staged through LDS.  A workgroup owns a
-// tile of RZ_TY x RZ_TX destination pixels.  The source rectangle the tile's taps touch (about
-// RZ_TY / fy + 2 rows of RZ_TX / fx + 2 pixels) is read with 16-byte buffer loads -- whole aligned
-// chunks of every source row, consecutive lanes on consecutive chunks, so each row segment is one
-// coalesced burst and every source byte is fetched once per tile instead of once per tap and channel
-// with single-byte loads -- into LDS rows of `pitch` bytes; chunks past the end of the image return
-// zero through the buffer's range check.  The column and row taps of the tile are computed once
-// (one thread each) into LDS tables.  Then a thread produces 4 neighbouring destination pixels:
-// per pixel and source row three aligned LDS dwords and two byte-align operations give the 6 bytes of
-// the two tap pixels; the 12 output bytes leave as one 12-byte store (consecutive lanes write
-// consecutive addresses).  Arithmetic is that of resize_linear_u8_kernel, bit for bit.
+// band of RZ_TY destination rows and walks it in tiles of RZ_TX pixels.  The source rectangle a
+// tile's taps touch (about RZ_TY / fy + 2 rows of RZ_TX / fx + 2 pixels) is fetched by LDS-DMA
+// (`buffer_load_dwordx4 ... lds`): whole aligned 16-byte chunks of every source row, consecutive
+// lanes on consecutive chunks, so each row segment is one coalesced burst and every source byte is
+// fetched once per tile instead of once per tap and channel with single-byte loads; chunks past the
+// end of the image return zero through the buffer's range check.  Two LDS buffers alternate: the
+// next tile's rectangle is in flight while the current tile is computed.  The band's row taps and
+// each tile's column taps are computed once (one thread each) into LDS tables.  A thread produces
+// 4 neighbouring destination pixels: per pixel and source row three aligned LDS dwords and two
+// byte-align operations give the 6 bytes of the two tap pixels, a byte permute pairs up each
+// channel, and the row value is one 16-bit dot product; the 12 output bytes leave as one 12-byte
+// store (consecutive lanes write consecutive addresses).  (One unaligned 8-byte LDS read per window
+// instead of three aligned dwords gives the same bytes but runs 1.5x slower.)
+// The band is walked along x by ONE workgroup on purpose: the RZ_TY destination rows of a band are
+// one contiguous piece of memory, so all partial cache lines between neighbouring tiles are
+// completed by the same workgroup, in the same L2, a few microseconds apart.  With neighbouring
+// tiles on different workgroups (round-robin over the XCDs, i.e. different L2s) the stores ran at
+// a third of the rate (ablation: 110 us for loads + stores against 73 us for the loads alone).
+// Arithmetic is that of resize_linear_u8_kernel, bit for bit.
 constexpr int RZ_TX = 128, RZ_TY = 8;
+constexpr int RZ_ROUNDS = 8;          // DMA rounds of 256 chunks per tile: rectangles of up to 32 KB
+
+struct Resize3Args {
+    const uint8_t* src;
+    uint8_t* dst;
+    double scale_x, scale_y;
+    int sh, sw, dh, dw;
+    int pitch;            // bytes per staged row (multiple of 16)
+    int max_rows;         // staged rows per tile
+    int buf_bytes;        // bytes per staging buffer (whole 4 KB pieces: a DMA round of 256 lanes)
+    unsigned inv_cpr;     // ceil(2^20 / chunks per row): chunk index -> row by multiplication
+    int dst_aligned;      // every destination row starts on a 4-byte boundary (12-byte stores allowed)
+};
 
 template <bool AREA2, bool REVERSE>
-__global__ __launch_bounds__(256) void resize3_lds_kernel(const uint8_t* __restrict__ src, int sh, int sw, double scale_x,
-                                                         double scale_y, uint8_t* __restrict__ dst, int dh, int dw,
-                                                         int pitch, int max_rows) {
+__global__ __launch_bounds__(256) void resize3_lds_kernel(Resize3Args a) {
 #if defined(__HIP_DEVICE_COMPILE__)
     extern __shared__ __attribute__((aligned(16))) uint8_t rz_lds[];
-    int2* coltab = reinterpret_cast<int2*>(rz_lds + (size_t)max_rows * pitch);   // (first tap column, w0 | w1 << 16)
-    int4* rowtab = reinterpret_cast<int4*>(coltab + RZ_TX);                       // (tap rows, b0 << 16, b1 << 16)
-    const int tid = threadIdx.x, b = blockIdx.z;
-    const int dy0 = blockIdx.y * RZ_TY, dx0 = blockIdx.x * RZ_TX;
-    const int ny = min(RZ_TY, dh - dy0), nx = min(RZ_TX, dw - dx0);
-    // one tap per thread: columns of the tile, then its rows
-    if (tid < nx) {
-        if (AREA2) {
-            coltab[tid] = make_int2(2 * (dx0 + tid), 0);
-        } else {
-            const Tap2 t = linear_tap(dx0 + tid, scale_x, sw);
-            coltab[tid] = make_int2(t.s0, t.w0 | (t.w1 << 16));
-        }
-    } else if (tid >= RZ_TX && tid - RZ_TX < ny) {
-        const int r = tid - RZ_TX;
-        if (AREA2) {
-            rowtab[r] = make_int4(2 * (dy0 + r), 2 * (dy0 + r) + 1, 0, 0);
-        } else {
-            const Tap2 t = linear_tap(dy0 + r, scale_y, sh);
-            rowtab[r] = make_int4(t.s0, t.s1, t.w0 << 16, t.w1 << 16);
-        }
-    }
-    __syncthreads();
-    // taps are monotonic: the tile's source rectangle starts at the first column / row tap
-    const int c_lo = coltab[0].x, r_lo = rowtab[0].x;
-    const int nrows = min(rowtab[ny - 1].y - r_lo + 1, max_rows);
+    int4* rowtab = reinterpret_cast<int4*>(rz_lds + 2 * (size_t)a.buf_bytes);   // [RZ_TY]: (tap rows, b0, b1)
+    int2* coltab = reinterpret_cast<int2*>(rowtab + RZ_TY);                      // [3][RZ_TX]: (first tap column, w0 | w1 << 16)
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), b = blockIdx.y;
+    const int sw = a.sw, sh = a.sh, dh = a.dh, dw = a.dw, pitch = a.pitch;
+    const int dy0 = blockIdx.x * RZ_TY;
+    const int ny = min(RZ_TY, dh - dy0);
+    const int ntiles = (dw + RZ_TX - 1) / RZ_TX;
+
     // the image as a buffer whose base is 16-byte aligned (the bytes before the image inside its first
     // chunk belong to the same allocation)
-    const uint8_t* img = src + (size_t)b * sh * sw * 3;
+    const uint8_t* img = a.src + (size_t)b * sh * sw * 3;
+    uint8_t* dimg = a.dst + (size_t)b * dh * dw * 3;
     const unsigned mis = (unsigned)(reinterpret_cast<uintptr_t>(img) & 15u);
     // The range ends at the end of the image's last 16-byte chunk: a 16-byte load is dropped as a whole
     // when it crosses the end of the range, and the bytes up to the chunk boundary lie in the same
@@ -124,38 +127,109 @@ __global__ __launch_bounds__(256) void resize3_lds_kernel(const uint8_t* __restr
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
         (void*)(img - mis), 0, (unsigned)(((size_t)sh * sw * 3 + mis + 15) & ~(size_t)15), 0x00020000);
     const int cpr = pitch >> 4;                       // 16-byte chunks per staged row
-    const unsigned origin = mis + (unsigned)(r_lo * sw + c_lo) * 3u;     // byte offset of (r_lo, c_lo) from the buffer base
     const unsigned row_bytes = (unsigned)sw * 3u;
-    typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
-    for (int i = tid; i < nrows * cpr; i += 256) {
-        const int r = i / cpr, ch = i - r * cpr;
-        const unsigned start = origin + (unsigned)r * row_bytes;
-        const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(rs, (start & ~15u) + (unsigned)ch * 16u, 0, 0);
-        *reinterpret_cast<u32x4_t*>(rz_lds + (size_t)r * pitch + ch * 16) = v;
+
+    // Which staged row and chunk lane `tid` moves in DMA round k does not depend on the tile: byte
+    // offset of the row from the rectangle's origin, and of the chunk inside the row.
+    // (24-bit multiplies throughout: full rate, and every factor is far below 2^24)
+    unsigned dma_row[RZ_ROUNDS], dma_chunk[RZ_ROUNDS];
+#pragma unroll
+    for (int k = 0; k < RZ_ROUNDS; ++k) {
+        const unsigned i = (unsigned)(k * 256 + tid);
+        const unsigned r = __umul24(i, a.inv_cpr) >> 20;
+        dma_row[k] = __umul24(r, row_bytes);
+        dma_chunk[k] = (i - __umul24(r, (unsigned)cpr)) * 16u;
     }
+
+    // column taps of tile j (one thread per destination column) into table j % 3 -- three tables,
+    // because tile j + 1's is written while slower waves may still be reading tile j - 1's; columns
+    // past the image repeat its last one, so a table is always full
+    auto col_taps = [&](int j) {
+        if (tid >= RZ_TX) return;
+        const int dx = min(j * RZ_TX + tid, dw - 1);
+        int2 e;
+        if (AREA2) {
+            e = make_int2(2 * dx, 0);
+        } else {
+            const Tap2 t = linear_tap(dx, a.scale_x, sw);
+            e = make_int2(t.s0, t.w0 | (t.w1 << 16));
+        }
+        coltab[(j % 3) * RZ_TX + tid] = e;
+    };
+    // row taps of the band, by the threads the column taps leave idle
+    if (tid >= RZ_TX && tid - RZ_TX < RZ_TY) {
+        const int dy = min(dy0 + tid - RZ_TX, dh - 1);
+        int4 e;
+        if (AREA2) {
+            e = make_int4(2 * dy, 2 * dy + 1, 0, 0);
+        } else {
+            const Tap2 t = linear_tap(dy, a.scale_y, sh);
+            e = make_int4(t.s0, t.s1, t.w0, t.w1);
+        }
+        rowtab[tid - RZ_TX] = e;
+    }
+    col_taps(0);
     __syncthreads();
+    // taps are monotonic: the source rectangle starts at the first row tap / first column tap
+    const int r_lo = rowtab[0].x;
+    const int nrows = min(rowtab[ny - 1].y - r_lo + 1, a.max_rows);
+    const int total = nrows * cpr;
+    // LDS-DMA of tile j's source rectangle into buffer j & 1 (its column table must be visible)
+    auto issue = [&](int j) {
+        const int c_lo = coltab[(j % 3) * RZ_TX].x;
+        const unsigned origin = mis + (unsigned)(r_lo * sw + c_lo) * 3u;
+        uint8_t* buf = rz_lds + (size_t)(j & 1) * a.buf_bytes;
+#pragma unroll
+        for (int k = 0; k < RZ_ROUNDS; ++k) {
+            if (k * 256 >= total) break;
+            const unsigned vo = k * 256 + tid < total ? ((origin + dma_row[k]) & ~15u) + dma_chunk[k] : 0x80000000u;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(
+                rs, (__attribute__((address_space(3))) void*)(buf + (size_t)(k * 256 + wave * 64) * 16), 16, vo, 0, 0, 0);
+        }
+    };
+    issue(0);
+
+    // this thread's destination row and 4-pixel group inside every tile, and the staged rows of its taps
     constexpr int GX = RZ_TX / 4;
-    for (int item = tid; item < ny * GX; item += 256) {
-        const int ry = item / GX, gx = (item - ry * GX) * 4;
-        if (gx >= nx) continue;
-        const int4 rt = rowtab[ry];
-        const int r0 = rt.x - r_lo, r1 = rt.y - r_lo;
+    const int ry = tid / GX, gx = (tid - ry * GX) * 4;
+    const int4 rt = rowtab[ry];
+    const unsigned r0 = (unsigned)(rt.x - r_lo), r1 = (unsigned)(rt.y - r_lo);
+    const unsigned rowpos0 = __umul24(r0, (unsigned)pitch), rowpos1 = __umul24(r1, (unsigned)pitch);
+    const unsigned rowoff0 = __umul24(r0, row_bytes), rowoff1 = __umul24(r1, row_bytes);
+    const unsigned orow = __umul24((unsigned)(dy0 + ry), (unsigned)dw);
+
+    for (int j = 0; j < ntiles; ++j) {
+        if (j + 1 < ntiles) col_taps(j + 1);
+        // This wave's part of tile j has landed.  Vector-memory operations retire in issue order and the
+        // stores of tile j - 1 were issued after the loads of tile j, so one operation may stay in flight
+        // -- the youngest, a store -- instead of every tile waiting out a write round trip.
+        if (j > 0 && 2 * wave < ny) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                                        // ... everyone's; the next tile's taps are visible
+        if (j + 1 < ntiles) issue(j + 1);                       // its buffer was last read while computing tile j - 1
+        const int dx0 = j * RZ_TX;
+        const int nx = min(RZ_TX, dw - dx0);
+        if (ry >= ny || gx >= nx) continue;
+        const int2* ctab = coltab + (j % 3) * RZ_TX;
+        const uint8_t* buf = rz_lds + (size_t)(j & 1) * a.buf_bytes;
+        const int c_lo = ctab[0].x;
+        const unsigned origin = mis + (unsigned)(r_lo * sw + c_lo) * 3u;
         // byte position of source column c_lo inside each of the two staged rows (their alignment differs)
-        const unsigned base0 = (unsigned)r0 * (unsigned)pitch + ((origin + (unsigned)r0 * row_bytes) & 15u);
-        const unsigned base1 = (unsigned)r1 * (unsigned)pitch + ((origin + (unsigned)r1 * row_bytes) & 15u);
+        const unsigned base0 = rowpos0 + ((origin + rowoff0) & 15u);
+        const unsigned base1 = rowpos1 + ((origin + rowoff1) & 15u);
         unsigned vout[12];
 #pragma unroll
         for (int px = 0; px < 4; ++px) {
-            const int2 ct = coltab[min(gx + px, nx - 1)];
+            const int2 ct = ctab[gx + px];
             const unsigned coff = (unsigned)(ct.x - c_lo) * 3u;
             unsigned lo[2], hi[2];                     // bytes 0..3 and 4..7 from the first tap pixel on, per row
 #pragma unroll
             for (int r = 0; r < 2; ++r) {
-                const unsigned a = (r ? base1 : base0) + coff;
-                const unsigned* q = reinterpret_cast<const unsigned*>(rz_lds + (a & ~3u));
+                const unsigned ad = (r ? base1 : base0) + coff;
+                const unsigned* q = reinterpret_cast<const unsigned*>(buf + (ad & ~3u));
                 const unsigned d0 = q[0], d1 = q[1], d2 = q[2];
-                lo[r] = __builtin_amdgcn_alignbyte(d1, d0, a & 3u);
-                hi[r] = __builtin_amdgcn_alignbyte(d2, d1, a & 3u);
+                lo[r] = __builtin_amdgcn_alignbyte(d1, d0, ad & 3u);
+                hi[r] = __builtin_amdgcn_alignbyte(d2, d1, ad & 3u);
             }
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
@@ -167,28 +241,30 @@ __global__ __launch_bounds__(256) void resize3_lds_kernel(const uint8_t* __restr
                 if (AREA2) {
                     v = ((p0 & 0xffffu) + (p0 >> 16) + (p1 & 0xffffu) + (p1 >> 16) + 2u) >> 2;
                 } else {
-                    const unsigned w0 = (unsigned)ct.y & 0xffffu, w1 = (unsigned)ct.y >> 16;
-                    const unsigned h0 = (p0 & 0xffffu) * w0 + (p0 >> 16) * w1;
-                    const unsigned h1 = (p1 & 0xffffu) * w0 + (p1 >> 16) * w1;
-                    // (b * (h >> 4)) >> 16 with b < 2^12, h >> 4 < 2^15: the high word of (b << 16) * (h >> 4)
-                    v = (__umulhi((unsigned)rt.z, h0 >> 4) + __umulhi((unsigned)rt.w, h1 >> 4) + 2u) >> 2;
+                    // row value S[s0] * w0 + S[s1] * w1: one dot product of 16-bit pairs
+                    typedef unsigned short u16x2_t __attribute__((ext_vector_type(2)));
+                    const u16x2_t wp = __builtin_bit_cast(u16x2_t, (unsigned)ct.y);
+                    const unsigned h0 = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2_t, p0), wp, 0u, false);
+                    const unsigned h1 = __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2_t, p1), wp, 0u, false);
+                    // b <= 2^11, h >> 4 < 2^15: 24-bit multiplies (32-bit ones run at a quarter of the rate)
+                    v = ((__umul24((unsigned)rt.z, h0 >> 4) >> 16) + (__umul24((unsigned)rt.w, h1 >> 4) >> 16) + 2u) >> 2;
                 }
                 vout[px * 3 + (REVERSE ? 2 - k : k)] = v;
             }
         }
-        uint8_t* o = dst + (((size_t)b * dh + dy0 + ry) * dw + dx0 + gx) * 3;
-        if (gx + 4 <= nx && (reinterpret_cast<uintptr_t>(o) & 3u) == 0) {
+        uint8_t* o = dimg + (orow + (unsigned)(dx0 + gx)) * 3u;
+        if (gx + 4 <= nx && a.dst_aligned) {
             typedef unsigned u32x3_t __attribute__((ext_vector_type(3)));
             u32x3_t w;
 #pragma unroll
-            for (int j = 0; j < 3; ++j)
-                w[j] = vout[4 * j] | (vout[4 * j + 1] << 8) | (vout[4 * j + 2] << 16) | (vout[4 * j + 3] << 24);
+            for (int q = 0; q < 3; ++q)
+                w[q] = vout[4 * q] | (vout[4 * q + 1] << 8) | (vout[4 * q + 2] << 16) | (vout[4 * q + 3] << 24);
             *reinterpret_cast<u32x3_t*>(o) = w;
         } else {
             const int nb = 3 * min(4, nx - gx);
 #pragma unroll
-            for (int j = 0; j < 12; ++j)
-                if (j < nb) o[j] = (uint8_t)vout[j];
+            for (int q = 0; q < 12; ++q)
+                if (q < nb) o[q] = (uint8_t)vout[q];
         }
     }
 #endif
@@ -305,20 +381,30 @@ int fd_resize_cvt_u8(fd_ctx* ctx, const uint8_t* src, int batch, int src_h, int 
     const int area2 = (scale_x == 2.0 && scale_y == 2.0 && src_w % 2 == 0 && src_h % 2 == 0) ? 1 : 0;
     fd::ProfScope scope(fd::as_stream(stream), "resize_linear_u8", 0.0,
                         (double)batch * channels * ((double)src_h * src_w + (double)dst_h * dst_w));
-    // 3-channel frames take the LDS-staged kernel whenever a tile's source rectangle fits in LDS (any
-    // scale from enlargements down to about 1/7); the per-pixel kernel is the general fallback.
+    // 3-channel frames take the LDS-staged kernel whenever two tiles' source rectangles fit in LDS (any
+    // scale from enlargements down to about 1/6); the per-pixel kernel is the general fallback.
+    static_assert(fd::RZ_TX / 4 * fd::RZ_TY == 256, "one 4-pixel group of a tile per thread");
     static const bool allow_lds = !(getenv("FD_RESIZE_LDS") && atoi(getenv("FD_RESIZE_LDS")) == 0);
     if (channels == 3 && allow_lds && (size_t)src_h * src_w * 3 < (1ull << 31) && batch <= 65535) {
-        const int max_rows = std::min(src_h, (int)std::ceil(fd::RZ_TY * scale_y) + 3);
+        fd::Resize3Args a;
+        a.src = src; a.dst = dst; a.scale_x = scale_x; a.scale_y = scale_y;
+        a.sh = src_h; a.sw = src_w; a.dh = dst_h; a.dw = dst_w;
+        a.max_rows = std::min(src_h, (int)std::ceil(fd::RZ_TY * scale_y) + 3);
         const int max_cols = std::min(src_w, (int)std::ceil(fd::RZ_TX * scale_x) + 3);
-        const int pitch = ((max_cols * 3 + 15 + 8) + 15) / 16 * 16;     // worst lead + the taps' 8-byte window, in whole chunks
-        const size_t smem = (size_t)max_rows * pitch + fd::RZ_TX * sizeof(int2) + fd::RZ_TY * sizeof(int4);
-        if (smem <= 64 * 1024) {
-            dim3 grid(fd::ceil_div(dst_w, fd::RZ_TX), fd::ceil_div(dst_h, fd::RZ_TY), batch);
+        a.pitch = ((max_cols * 3 + 15 + 8) + 15) / 16 * 16;     // worst lead + the taps' 8-byte window, in whole chunks
+        const int cpr = a.pitch / 16;
+        const int chunks = a.max_rows * cpr;
+        a.buf_bytes = (chunks + 255) / 256 * 4096;
+        a.inv_cpr = (unsigned)(((1u << 20) + cpr - 1) / cpr);
+        a.dst_aligned = ((reinterpret_cast<uintptr_t>(dst) & 3u) == 0 && ((size_t)dst_w * 3) % 4 == 0 &&
+                         ((size_t)dst_h * dst_w * 3) % 4 == 0) ? 1 : 0;
+        const size_t smem = 2 * (size_t)a.buf_bytes + 3 * fd::RZ_TX * sizeof(int2) + fd::RZ_TY * sizeof(int4);
+        // chunk -> row by multiplication is exact for chunk indices below 2^20 / cpr and needs cpr >= 2
+        if (smem <= 64 * 1024 && cpr >= 2 && chunks <= fd::RZ_ROUNDS * 256 && chunks + 256 <= (1 << 20) / cpr &&
+            (size_t)dst_h * dst_w * 3 < (1ull << 31) && dst_h < (1 << 23) && dst_w < (1 << 23)) {
+            dim3 grid(fd::ceil_div(dst_h, fd::RZ_TY), batch);
             const hipStream_t st = fd::as_stream(stream);
-#define FD_RZ(A2, REV)                                                                                          \
-    hipLaunchKernelGGL((fd::resize3_lds_kernel<A2, REV>), grid, dim3(256), smem, st, src, src_h, src_w, scale_x, \
-                       scale_y, dst, dst_h, dst_w, pitch, max_rows)
+#define FD_RZ(A2, REV) hipLaunchKernelGGL((fd::resize3_lds_kernel<A2, REV>), grid, dim3(256), smem, st, a)
             if (area2) { if (reverse_channels) FD_RZ(true, true); else FD_RZ(true, false); }
             else { if (reverse_channels) FD_RZ(false, true); else FD_RZ(false, false); }
 #undef FD_RZ
