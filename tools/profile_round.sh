@@ -1,0 +1,23 @@
+#!/bin/bash
+# Kernel statistics and HBM traffic of the benchmark for profiles/ (run on the GPU box):
+#   bash tools/profile_round.sh <tag>      e.g. r02_b
+# 1. rocprofv3 --kernel-trace --stats of the default `python3 bench.py` (both precisions)
+# 2. two PMC passes (FETCH_SIZE, WRITE_SIZE: they do not fit one pass) of a short run at the same
+#    micro-batch, summarised by tools/pmc_summary.py with the library's source hash.
+set -e
+TAG=$1
+R=$GRAFT_REPO_ROOT
+OUT=$R/gpurun_out/$TAG
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -- python3 $R/bench.py > $OUT/bench_under_rocprof.json 2> $OUT/kt.err
+cp $(ls $OUT/kt/*/*kernel_stats.csv | head -1) $OUT/kernel_stats.csv
+rm -f $OUT/kt/*/*kernel_trace.csv
+SHORT="--frames 16 --steps 1 --warmup 1 --no-cpu-baseline --no-profile --check-frames 0 --split-streams 1"
+timeout -s KILL 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 $R/bench.py $SHORT > $OUT/pmc_fetch.json 2> $OUT/pmc_fetch.err
+timeout -s KILL 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 $R/bench.py $SHORT > $OUT/pmc_write.json 2> $OUT/pmc_write.err
+cd $R
+python3 tools/pmc_summary.py $(ls $OUT/pmc_fetch/*/*counter_collection.csv | head -1) $(ls $OUT/pmc_write/*/*counter_collection.csv | head -1) $OUT/pmc_traffic.json > $OUT/pmc_summary.txt
+rm -rf $OUT/pmc_fetch $OUT/pmc_write $OUT/kt
+timeout -k 10 600 python3 bench.py > $OUT/bench.json 2> $OUT/bench.err
+cat $OUT/pmc_summary.txt
