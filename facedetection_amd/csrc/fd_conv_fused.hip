@@ -26,7 +26,8 @@ namespace fd {
 // unit), and the compute-heavy and the traffic-heavy phase of co-resident workgroups overlap.
 // LDS: [epilogue staging 18 KB | A operand 32 KB | weight chunk 16 KB]; the K loop of the 3x3
 // uses the first 48 KB as its two pipeline stages before that.
-template <int BM, int MID>
+// F32: float32 operands on the fp32 matrix cores (same LDS image: a row of a K-step is 32 floats).
+template <int BM, int MID, bool F32>
 __global__ __launch_bounds__(256, 2) void conv_tail_fused_kernel(SplitKArgs a, SplitKArgs c, unsigned x_bytes,
                                                                 unsigned w_bytes, unsigned w3_bytes) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -132,7 +133,8 @@ __global__ __launch_bounds__(256, 2) void conv_tail_fused_kernel(SplitKArgs a, S
 #define FD_STEP(CUR, KT)                                                                          \
     do {                                                                                          \
         if ((KT) + 1 < nk) FD_ISSUE((KT) + 1, (CUR) ^ 1);                                         \
-        split_mma_step<BM, BN>(sbase + (CUR) * STAGE * 4, a_off, b_off, acc);                     \
+        if (F32) f32_mma_step<BM, BN>(sbase + (CUR) * STAGE * 4, a_off, b_off, acc);              \
+        else split_mma_step<BM, BN>(sbase + (CUR) * STAGE * 4, a_off, b_off, acc);                \
         wait_vmcnt<0>();                                                                          \
         __syncthreads();                                                                          \
     } while (0)
@@ -178,15 +180,22 @@ __global__ __launch_bounds__(256, 2) void conv_tail_fused_kernel(SplitKArgs a, S
                 const int row = wm * (BM / 2) + mi * 32 + lrow2;
                 const f32x4 v0 = *reinterpret_cast<const f32x4*>(&Cs[lrow2 * LDC + ecol]);
                 const f32x4 v1 = *reinterpret_cast<const f32x4*>(&Cs[lrow2 * LDC + ecol + 4]);
-                f16x8 hi, lo;
-                split8(v0, v1, hi, lo, bad2);
                 char* kstep = aimg + wn * (BM * 128);
-                const int off = row * 128 + (((ecol >> 3) ^ ((row >> 1) & 7)) * 16);
-                *reinterpret_cast<f16x8*>(kstep + off) = hi;
-                *reinterpret_cast<f16x8*>(kstep + (off ^ 64)) = lo;      // lo chunk = hi chunk + 4
+                if (F32) {
+                    // 8 channels = two 16-byte chunks of the row's 32 floats
+                    const int c4 = ecol >> 2, swz = (row >> 1) & 7;
+                    *reinterpret_cast<f32x4*>(kstep + row * 128 + ((c4 ^ swz) * 16)) = v0;
+                    *reinterpret_cast<f32x4*>(kstep + row * 128 + (((c4 + 1) ^ swz) * 16)) = v1;
+                } else {
+                    f16x8 hi, lo;
+                    split8(v0, v1, hi, lo, bad2);
+                    const int off = row * 128 + (((ecol >> 3) ^ ((row >> 1) & 7)) * 16);
+                    *reinterpret_cast<f16x8*>(kstep + off) = hi;
+                    *reinterpret_cast<f16x8*>(kstep + (off ^ 64)) = lo;      // lo chunk = hi chunk + 4
+                }
             }
         }
-        split_report(c.clamped, bad2);
+        if (!F32) split_report(c.clamped, bad2);
     }
 
     // ---- phase 3: the 1x1 convolution, 64 output channels at a time ----
@@ -222,8 +231,10 @@ __global__ __launch_bounds__(256, 2) void conv_tail_fused_kernel(SplitKArgs a, S
         f32x4 acc3[T::AM][T::AN];                                                                 \
         _Pragma("unroll") for (int mi = 0; mi < T::AM; ++mi)                                      \
             _Pragma("unroll") for (int ni = 0; ni < T::AN; ++ni) acc3[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f}; \
-        _Pragma("unroll") for (int kk = 0; kk < MID / 32; ++kk)                                   \
-            split_mma_step<BM, BN>(sbase, a3_off[kk], b3_off[kk], acc3);                          \
+        _Pragma("unroll") for (int kk = 0; kk < MID / 32; ++kk) {                                 \
+            if (F32) f32_mma_step<BM, BN>(sbase, a3_off[kk], b3_off[kk], acc3);                   \
+            else split_mma_step<BM, BN>(sbase, a3_off[kk], b3_off[kk], acc3);                     \
+        }                                                                                         \
         __syncthreads();               /* every wave is done reading the weight chunk */          \
         if ((CH) + 1 < nch) {                                                                     \
             FD_WEIGHTS((CH) + 1);                                                                 \
@@ -251,7 +262,8 @@ __global__ __launch_bounds__(256, 2) void conv_tail_fused_kernel(SplitKArgs a, S
 int conv_tail_fused_forward(const SplitConvParams& p2, const SplitConvParams& p3, const void* x_split, int batch, int h,
                             int w, const float* residual, const SplitConvOut& out, hipStream_t stream, bool* taken) {
     *taken = false;
-    if (p2.f32 || p3.f32) return FD_OK;          // split operands only
+    if (p2.f32 != p3.f32) return FD_OK;
+    const bool f32 = p2.f32;
     const ConvShape &s2 = p2.s, &s3 = p3.s;
     if (!(s2.cin == 64 && s2.cout == 64 && s2.kh == 3 && s2.kw == 3 && s2.kwp == 3 && s2.stride == 1 && s2.pad == 1 &&
           p2.relu && s3.cin == 64 && s3.kh == 1 && s3.kw == 1 && s3.stride == 1 && s3.pad == 0 && s3.cout % 64 == 0))
@@ -267,18 +279,22 @@ int conv_tail_fused_forward(const SplitConvParams& p2, const SplitConvParams& p3
     a.pre_scale = a.pre_shift = nullptr; a.w_inv_scale = p2.w_inv_scale;
     a.H = h; a.W = w; a.Cin = 64; a.Ho = h; a.Wo = w; a.Cout = 64; a.KW = 3; a.stride = 1; a.pad = 1; a.K = s2.k();
     a.M = (int)m_ll; a.relu = 1; a.tiles_n = 1;
-    a.ksplit = 1; a.kchunk = a.K / SBK; a.partial = nullptr; a.clamped = out.clamped; a.f32 = 0;
+    a.ksplit = 1; a.kchunk = a.K / SBK; a.partial = nullptr; a.clamped = out.clamped; a.f32 = f32 ? 1 : 0;
     c = a;
     c.x = nullptr; c.w = static_cast<const uint8_t*>(p3.w); c.bias = p3.bias; c.res = residual; c.y32 = out.y32;
     c.ysplit = static_cast<uint8_t*>(out.ysplit); c.post_scale = out.post_scale; c.post_shift = out.post_shift;
     c.w_inv_scale = p3.w_inv_scale; c.Cin = 64; c.Cout = s3.cout; c.KW = 1; c.pad = 0; c.K = 64; c.relu = p3.relu;
     c.tiles_n = s3.cout / 64;
     const int tiles_m = ceil_div(a.M, 128);
-    ProfScope scope(stream, "conv_tail_fused", 2.0 * a.M * 64.0 * (double)a.K + 2.0 * a.M * (double)s3.cout * 64.0,
+    ProfScope scope(stream, f32 ? "conv_tail_fused_f32" : "conv_tail_fused", 2.0 * a.M * 64.0 * (double)a.K + 2.0 * a.M * (double)s3.cout * 64.0,
                     4.0 * 64.0 * a.M + 4.0 * 64.0 * (a.K + s3.cout) +
                         4.0 * a.M * s3.cout * ((c.res ? 1.0 : 0.0) + (c.y32 ? 1.0 : 0.0) + (c.ysplit ? 1.0 : 0.0)));
-    hipLaunchKernelGGL((conv_tail_fused_kernel<128, 64>), dim3(tiles_m), dim3(256), 0, stream, a, c, (unsigned)x_bytes,
-                       (unsigned)w_bytes, (unsigned)w3_bytes);
+    if (f32)
+        hipLaunchKernelGGL((conv_tail_fused_kernel<128, 64, true>), dim3(tiles_m), dim3(256), 0, stream, a, c,
+                           (unsigned)x_bytes, (unsigned)w_bytes, (unsigned)w3_bytes);
+    else
+        hipLaunchKernelGGL((conv_tail_fused_kernel<128, 64, false>), dim3(tiles_m), dim3(256), 0, stream, a, c,
+                           (unsigned)x_bytes, (unsigned)w_bytes, (unsigned)w3_bytes);
     FD_LAUNCH_CHECK();
     *taken = true;
     return FD_OK;

@@ -58,3 +58,29 @@ def test_fused_unit_tensors_match_elementwise(monkeypatch):
     finally:
         ref.close()
         new.close()
+
+
+def test_float32_fused_tail_matches_the_separate_float32_kernels():
+    """precision="f32": an ordinary pass runs the 3x3 + 1x1 tail of each 64-channel unit as one kernel
+    (the tensor between them stays in LDS as float32); a layer-by-layer pass runs them as two.  Same
+    float32 products, and the 1x1 sums its 64 terms in the same order, so unit outputs agree to
+    rounding noise of the 3x3's different summation order."""
+    from facedetection_amd.detection import Detector
+    lay = Detector("synthetic:0", 0, own_context=True, precision="f32")
+    new = Detector("synthetic:0", 0, own_context=True, precision="f32")
+    lay.keep_tensors(True)
+    new.keep_tensors(True, production=True)
+    rng = np.random.default_rng(11)
+    try:
+        for (b, h, w) in SIZES:
+            frames = rng.integers(0, 256, size=(b, h, w, 3), dtype=np.uint8)
+            lay.forward(frames)
+            new.forward(frames)
+            for name in ("stage1_unit1", "stage1_unit2", "stage1_unit3", "feat"):
+                want, got = lay.tensor(name), new.tensor(name)
+                assert want.shape == got.shape
+                scale = float(np.abs(want).max())
+                assert float(np.abs(got - want).max()) <= 4e-6 * scale, (name, (b, h, w))
+    finally:
+        lay.close()
+        new.close()
