@@ -356,6 +356,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) void conv_split_gld
         const int row = (wave + WAVES * i) * 8 + lrow;
         const int chunk = lpos ^ ((row >> 1) & 7);
         bvo[i] = (unsigned)((tile_n * BN + row) * a.K * 4 + chunk * 16);
+        if (a.wbatch_tiles > 0) bvo[i] += (unsigned)(tile_m / a.wbatch_tiles) * a.wbatch_bytes;
     }
     // this workgroup's K-steps: kb .. kb + nk - 1 (everything unless the launch splits K)
     const int kb = ks * a.kchunk;
@@ -918,6 +919,26 @@ static int split_conv_dispatch(const SplitConvParams& p, const void* x_split, co
     if (s.cout > 64 && t128 >= 384) return launch_split<128, 128, false>(a, stream);
     if (t12864 >= 384) return launch_split<128, 64, false>(a, stream);
     return launch_split<64, 64, false>(a, stream);
+}
+
+int gemm_f32_batched(const float* a_mat, const float* w, int nb, int rows_pad, int k, int cout, int cout_pad, float* y,
+                     hipStream_t stream) {
+    FD_REQUIRE(a_mat && w && y && nb > 0 && rows_pad > 0 && rows_pad % 128 == 0 && k % 32 == 0 && cout % 8 == 0 &&
+                   cout_pad % 128 == 0 && cout <= cout_pad, "gemm_f32_batched: bad arguments");
+    const size_t x_bytes = (size_t)nb * rows_pad * k * 4, w_bytes = (size_t)nb * cout_pad * k * 4;
+    FD_REQUIRE(x_bytes < (1ull << 31) && w_bytes < (1ull << 31) && (long long)nb * rows_pad < (1ll << 29),
+               "gemm_f32_batched: operands beyond the 2^31-byte reach of the buffer-addressed kernel");
+    SplitKArgs a;
+    a.x = reinterpret_cast<const uint8_t*>(a_mat);
+    a.w = reinterpret_cast<const uint8_t*>(w);
+    a.bias = nullptr; a.res = nullptr; a.y32 = nullptr; a.ysplit = reinterpret_cast<uint8_t*>(y);
+    a.post_scale = a.post_shift = nullptr; a.pre_scale = a.pre_shift = nullptr; a.w_inv_scale = 1.f;
+    a.H = 1; a.W = 1; a.Cin = k; a.Ho = 1; a.Wo = 1; a.Cout = cout; a.KW = 1; a.stride = 1; a.pad = 0; a.K = k;
+    a.M = nb * rows_pad; a.relu = 0; a.tiles_n = 0; a.ksplit = 1; a.kchunk = k / SBK; a.partial = nullptr;
+    a.clamped = nullptr; a.f32 = 1;
+    a.wbatch_tiles = rows_pad / 128;
+    a.wbatch_bytes = (unsigned)((size_t)cout_pad * k * 4);
+    return launch_split_glds<128, 128, 2, 4, true>(a, x_bytes, w_bytes, stream);
 }
 
 int split_conv_forward(const SplitConvParams& p, const void* x_split, int batch, int h, int w, const float* residual,

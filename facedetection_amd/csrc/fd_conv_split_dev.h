@@ -26,6 +26,10 @@ struct SplitKArgs {
     int ksplit, kchunk;
     float* partial;
     unsigned* clamped;       // device counter of values outside the fp16 range met while splitting (may be NULL)
+    // batched GEMM (direct-to-LDS kernel only): row tiles [b * wbatch_tiles, (b + 1) * wbatch_tiles) multiply
+    // the weight set at byte offset b * wbatch_bytes (0 tiles: one weight set)
+    int wbatch_tiles = 0;
+    unsigned wbatch_bytes = 0;
     int f32;                 // float32 operands: x, w and the "split" output are plain float32 tensors (same
                              // 4 bytes per element, so the same addressing; 128-byte rows of 32 floats)
 };

@@ -24,6 +24,7 @@ struct Unit {
     ConvParams conv1, conv2, conv3, sc;
     SplitConvParams s_conv1, s_conv2, s_conv3, s_sc;   // split (f16x3) operands
     SplitConvParams f_conv1, f_conv2, f_conv3, f_sc;   // float32 operands on the same kernels
+    WinoConvParams w_conv2;                            // conv2 in Winograd form (float32 precision; wide stride-1 layers only)
     const float *bn1_scale = nullptr, *bn1_shift = nullptr;   // the unit's input BatchNorm (device)
     bool has_sc = false;
 };
@@ -36,7 +37,7 @@ struct Tap {
 
 enum NetBuf {
     NB_STAGED = 0, NB_CONV0, NB_XA, NB_XB, NB_T1, NB_T2, NB_SC, NB_RPN_HID, NB_RPN_OUT, NB_ROIS, NB_ROI_SCORES,
-    NB_POOLED, NB_X4A, NB_X4B, NB_FLAT, NB_CLS, NB_BOX, NB_COUNTS, NB_ACT_A, NB_ACT_B, NB_SPLITK, NB_COUNT
+    NB_POOLED, NB_X4A, NB_X4B, NB_FLAT, NB_CLS, NB_BOX, NB_COUNTS, NB_ACT_A, NB_ACT_B, NB_SPLITK, NB_WINO_V, NB_WINO_M, NB_COUNT
 };
 
 }  // namespace fd
@@ -51,6 +52,8 @@ struct fd_detector {
     fd::ConvParams rpn_conv, rpn_out;
     fd::SplitConvParams s_conv0, s_rpn_conv, s_rpn_out;
     fd::SplitConvParams f_rpn_conv, f_rpn_out;
+    fd::WinoConvParams w_rpn_conv;       // the RPN's 3x3 convolution in Winograd form (float32 precision)
+    bool winograd = true;                // float32 precision: use it (environment variable FD_WINOGRAD=0: direct)
     int precision = FD_PRECISION_F16X3;
     const float *bn1_scale = nullptr, *bn1_shift = nullptr;
     const float *w_cls = nullptr, *b_cls = nullptr, *w_box = nullptr, *b_box = nullptr;
@@ -212,6 +215,17 @@ static int build_unit(fd_detector* d, const ParamTable& t, const std::string& na
     u->bn1_shift = pre_h;
     FD_TRY(make_conv(d, w2->data_host, mid, shape(mid, mid, 3, stride, 1), &s3, &h3, 1, &u->conv2, &u->s_conv2, &u->f_conv2));
     FD_TRY(make_conv(d, w3->data_host, mid, shape(mid, cout, 1, 1, 0), nullptr, nullptr, 0, &u->conv3, &u->s_conv3, &u->f_conv3));
+    // Winograd form of the 3x3 where it pays: at 256 channels the 16 GEMMs are long enough to run near
+    // the matrix peak and the transforms (4x the tensor size each way) cost less than the multiplies saved
+    if (stride == 1 && mid == 256) {
+        std::vector<float> uw;
+        int cout_pad = 0;
+        FD_TRY(wino_pack_weights(w2->data_host, mid, mid, s3.data(), &uw, &cout_pad));
+        float* ud = nullptr;
+        FD_TRY(upload(d, uw.data(), uw.size(), &ud));
+        u->w_conv2.cin = mid; u->w_conv2.cout = mid; u->w_conv2.cout_pad = cout_pad;
+        u->w_conv2.u = ud; u->w_conv2.bias = u->f_conv2.bias; u->w_conv2.relu = 1;
+    }
     u->has_sc = !dim_match;
     if (u->has_sc) {
         const fd_param* ws = t.get(name + "_sc_weight", (int64_t)cout * cin);
@@ -253,6 +267,15 @@ static int build(fd_detector* d, const ParamTable& t) {
         if (!w || !b) return FD_ERR_PARAM;
         std::vector<float> bias(b->data_host, b->data_host + 512);
         FD_TRY(make_conv(d, w->data_host, 1024, shape(1024, 512, 3, 1, 1), nullptr, &bias, 1, &d->rpn_conv, &d->s_rpn_conv, &d->f_rpn_conv));
+        {
+            std::vector<float> u;
+            int cout_pad = 0;
+            FD_TRY(wino_pack_weights(w->data_host, 512, 1024, nullptr, &u, &cout_pad));
+            float* ud = nullptr;
+            FD_TRY(upload(d, u.data(), u.size(), &ud));
+            d->w_rpn_conv.cin = 1024; d->w_rpn_conv.cout = 512; d->w_rpn_conv.cout_pad = cout_pad;
+            d->w_rpn_conv.u = ud; d->w_rpn_conv.bias = d->f_rpn_conv.bias; d->w_rpn_conv.relu = 1;
+        }
         const int A = d->prop.num_ratios * d->prop.num_scales;
         const fd_param* wc = t.get("rpn_cls_score_weight", 2ll * A * 512);
         const fd_param* bc = t.get("rpn_cls_score_bias", 2 * A);
@@ -473,6 +496,13 @@ static int run_unit_split(Plan& pl, const Unit& u, const char* name, const void*
     float* t1 = pl.buf(NB_T1, (size_t)n * h * w * mid);
     float* t2 = pl.buf(NB_T2, (size_t)n * ho * wo * mid);
     const float* res = xraw;
+    const bool wino2 = pl.f32 && !pl.d->layerwise() && pl.d->winograd && u.w_conv2.u && wino_fits(u.w_conv2, n, h, w);
+    float *wino_v = nullptr, *wino_m = nullptr;
+    if (wino2) {
+        const size_t tp = (size_t)wino_patches_padded(n, h, w);
+        wino_v = pl.buf(NB_WINO_V, 16 * tp * u.w_conv2.cin);
+        wino_m = pl.buf(NB_WINO_M, 16 * tp * u.w_conv2.cout);
+    }
     // the projection unit of the 64-channel stage as one kernel: shortcut and main branch are
     // accumulated together, so neither the shortcut tensor nor t1/t2 exist
     bool whole_proj = false;
@@ -513,7 +543,8 @@ static int run_unit_split(Plan& pl, const Unit& u, const char* name, const void*
             if (!pl.d->layerwise())
                 FD_TRY(conv_tail_fused_forward(c2, c3, t1, n, h, w, res, o3, pl.stream, &fused));
             if (!fused) {
-                FD_TRY(split_conv_forward(c2, t1, n, h, w, nullptr, o2, pl.stream));
+                if (wino2) FD_TRY(wino_conv_forward(u.w_conv2, t1, n, h, w, wino_v, wino_m, t2, pl.stream));
+                else FD_TRY(split_conv_forward(c2, t1, n, h, w, nullptr, o2, pl.stream));
                 FD_TRY(split_conv_forward(c3, t2, n, ho, wo, res, o3, pl.stream));
             }
         }
@@ -607,11 +638,21 @@ static int run_graph_split(Plan& pl, const uint8_t* frames, int B, int H, int W,
     const int A = d->prop.num_ratios * d->prop.num_scales;
     float* hid = pl.buf(NB_RPN_HID, (size_t)B * fh * fw * 512);
     float* rout = pl.buf(NB_RPN_OUT, (size_t)B * fh * fw * 6 * A);
+    // float32 precision: the 3x3 convolution runs in Winograd form (4/9 of the multiplies) unless tensors
+    // are inspected layer by layer
+    const bool wino = f32 && !layerwise && d->winograd && wino_fits(d->w_rpn_conv, B, fh, fw);
+    float *wino_v = nullptr, *wino_m = nullptr;
+    if (wino) {
+        const size_t tp = (size_t)wino_patches_padded(B, fh, fw);
+        wino_v = pl.buf(NB_WINO_V, 16 * tp * d->w_rpn_conv.cin);
+        wino_m = pl.buf(NB_WINO_M, 16 * tp * d->w_rpn_conv.cout);
+    }
     if (!pl.dry) {
         SplitConvOut o1 = pl.out(), o2 = pl.out();
         o1.ysplit = hid;
         o2.y32 = rout;
-        FD_TRY(split_conv_forward(f32 ? d->f_rpn_conv : d->s_rpn_conv, feat_split, B, fh, fw, nullptr, o1, pl.stream));
+        if (wino) FD_TRY(wino_conv_forward(d->w_rpn_conv, feat, B, fh, fw, wino_v, wino_m, hid, pl.stream));
+        else FD_TRY(split_conv_forward(f32 ? d->f_rpn_conv : d->s_rpn_conv, feat_split, B, fh, fw, nullptr, o1, pl.stream));
         FD_TRY(split_conv_forward(f32 ? d->f_rpn_out : d->s_rpn_out, hid, B, fh, fw, nullptr, o2, pl.stream));
     }
     pl.tap("rpn_out", rout, B, fh, fw, 6 * A);
@@ -754,6 +795,7 @@ int fd_detector_create(fd_ctx* ctx, const fd_param* params, int n_params, const 
     fd_detector* d = new fd_detector();
     d->ctx = ctx;
     if (const char* e = getenv("FD_FUSE_UNITS")) d->fuse_units = atoi(e);
+    if (const char* e = getenv("FD_WINOGRAD")) d->winograd = atoi(e) != 0;
     d->prop = *cfg;
     const int rc = fd::build(d, t);
     if (rc != FD_OK) {

