@@ -224,15 +224,33 @@ int sort_pairs_u64(fd_ctx* ctx, uint64_t* ka, uint32_t* va, uint64_t* kb, uint32
 // ---------------------------------------------------------------------------------
 constexpr int NMS_PANEL_CHUNKS = 64;
 
+__device__ __forceinline__ uint64_t wave_uniform_u64(uint64_t v) {
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v);
+    const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+    return ((uint64_t)hi << 32) | lo;
+}
+
 template <typename T>
 __global__ __launch_bounds__(64) void nms_mask_kernel(const T* __restrict__ boxes, const int32_t* __restrict__ counters,
                                                       int cap, int words, int chunk0, int panel_rows, int max_keep,
-                                                      T thresh, uint64_t* __restrict__ mask) {
+                                                      T thresh, const uint64_t* __restrict__ removed_g,
+                                                      uint64_t* __restrict__ mask) {
     const int col = chunk0 + blockIdx.x, rowc = chunk0 + blockIdx.y, seg = blockIdx.z;
     if (col < rowc) return;
     if (max_keep > 0 && counters[seg * CNT_STRIDE + CNT_KEEP] >= max_keep) return;
     const int n = counters[seg * CNT_STRIDE + CNT_CAND];
     if (rowc * 64 >= n || col * 64 >= n) return;
+    // Candidates already suppressed by boxes kept in earlier panels need neither a mask row (only rows of
+    // kept boxes are ever read) nor mask bits as columns (they are removed whatever the bit says): a block
+    // whose 64 rows or 64 columns are all gone exits, the others skip dead rows and visit live columns only.
+    // Words this leaves unwritten or incomplete are read back only for dead rows, or OR-ed into bitmap words
+    // whose live bits they cannot change.
+    uint64_t dead_rows = 0ull, dead_cols = 0ull;
+    if (removed_g) {
+        dead_rows = removed_g[(size_t)seg * words + rowc];
+        dead_cols = removed_g[(size_t)seg * words + col];
+        if (dead_rows == ~0ull || dead_cols == ~0ull) return;
+    }
     __shared__ T cb[64][5];
     const int t = threadIdx.x;
     const T* segb = boxes + (size_t)seg * cap * 4;
@@ -250,14 +268,24 @@ __global__ __launch_bounds__(64) void nms_mask_kernel(const T* __restrict__ boxe
     }
     __syncthreads();
     const int i = rowc * 64 + t;
-    if (i >= n) return;
+    if (i >= n || ((dead_rows >> t) & 1ull)) return;
     const T x1 = segb[(size_t)i * 4 + 0], y1 = segb[(size_t)i * 4 + 1];
     const T x2 = segb[(size_t)i * 4 + 2], y2 = segb[(size_t)i * 4 + 3];
     const T area = (x2 - x1 + T(1)) * (y2 - y1 + T(1));
     const int jn = min(64, n - col * 64);
     const int j0 = (col == rowc) ? t + 1 : 0;
     uint64_t bits = 0;
-    for (int j = j0; j < jn; ++j) {
+    const bool fast_ok = thresh > T(0);
+    const T margin_lo = sizeof(T) == 4 ? T(1.0 - 1.0 / (1 << 20)) : T(1.0 - 1.0 / (1ll << 48));
+    const T margin_hi = sizeof(T) == 4 ? T(1.0 + 1.0 / (1 << 20)) : T(1.0 + 1.0 / (1ll << 48));
+    // live columns of this block (uniform over the wave: a scalar loop over the set bits)
+    uint64_t live = ~dead_cols;
+    if (jn < 64) live &= ~(~0ull << jn);
+    live = wave_uniform_u64(live);
+    while (live) {
+        const int j = __ffsll((long long)live) - 1;
+        live &= live - 1;
+        if (j < j0) continue;
         const T xx1 = (x1 > cb[j][0]) ? x1 : cb[j][0];
         const T yy1 = (y1 > cb[j][1]) ? y1 : cb[j][1];
         const T xx2 = (x2 < cb[j][2]) ? x2 : cb[j][2];
@@ -266,16 +294,20 @@ __global__ __launch_bounds__(64) void nms_mask_kernel(const T* __restrict__ boxe
         const T iw = (dw > T(0)) ? dw : T(0);
         const T ih = (dh > T(0)) ? dh : T(0);
         const T inter = iw * ih;
-        const T iou = inter / (area + cb[j][4] - inter);
-        if (!(iou <= thresh)) bits |= 1ull << j;
+        const T den = area + cb[j][4] - inter;
+        // The reference's test is  inter / den <= thresh  with a rounded quotient.  Far from the threshold
+        // the division is not needed: the rounded product p = thresh * den is within one rounding of the
+        // true one, so inter below p by more than a few units in the last place means a true quotient below
+        // thresh (and a rounded one <= thresh), inter above it by as much a rounded quotient > thresh.
+        // Only the pairs in between (and degenerate denominators) take the exact division.
+        const T p = thresh * den;
+        bool sup;
+        if (fast_ok && den > T(0) && inter < p * margin_lo) sup = false;
+        else if (fast_ok && den > T(0) && inter > p * margin_hi) sup = true;
+        else sup = !(inter / den <= thresh);
+        if (sup) bits |= 1ull << j;
     }
     mask[((size_t)seg * panel_rows + (i - chunk0 * 64)) * words + col] = bits;
-}
-
-__device__ __forceinline__ uint64_t wave_uniform_u64(uint64_t v) {
-    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v);
-    const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
-    return ((uint64_t)hi << 32) | lo;
 }
 
 // Serial part, one workgroup per image and panel.  Chunk c (64 candidates) of the panel can be
@@ -434,7 +466,8 @@ static int nms_sorted_ws(const T* cand_boxes, int32_t* counters, int cap, int ns
             ProfScope scope(stream, "nms_mask", 0.0,
                             (double)nseg * (rows_here * 64.0 * cols / 8.0 * 0.5 + 4.0 * sizeof(T) * cols));
             hipLaunchKernelGGL(nms_mask_kernel<T>, dim3(words - chunk0, rows_here, nseg), dim3(64), 0, stream,
-                               cand_boxes, counters, cap, words, chunk0, panel_rows, max_keep, thresh, mask);
+                               cand_boxes, counters, cap, words, chunk0, panel_rows, max_keep, thresh,
+                               (multi && chunk0 > 0) ? removed_g : nullptr, mask);
             FD_LAUNCH_CHECK();
         }
         {

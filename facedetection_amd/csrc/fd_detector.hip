@@ -215,9 +215,10 @@ static int build_unit(fd_detector* d, const ParamTable& t, const std::string& na
     u->bn1_shift = pre_h;
     FD_TRY(make_conv(d, w2->data_host, mid, shape(mid, mid, 3, stride, 1), &s3, &h3, 1, &u->conv2, &u->s_conv2, &u->f_conv2));
     FD_TRY(make_conv(d, w3->data_host, mid, shape(mid, cout, 1, 1, 0), nullptr, nullptr, 0, &u->conv3, &u->s_conv3, &u->f_conv3));
-    // Winograd form of the 3x3 where it pays: at 256 channels the 16 GEMMs are long enough to run near
+    // Winograd form of the 3x3 where it pays: from 256 channels on the 16 GEMMs are long enough to run near
     // the matrix peak and the transforms (4x the tensor size each way) cost less than the multiplies saved
-    if (stride == 1 && mid == 256) {
+    // (the 256-channel stage and the stride-1 units of the ROI head)
+    if (stride == 1 && mid >= 256) {
         std::vector<float> uw;
         int cout_pad = 0;
         FD_TRY(wino_pack_weights(w2->data_host, mid, mid, s3.data(), &uw, &cout_pad));
@@ -496,7 +497,10 @@ static int run_unit_split(Plan& pl, const Unit& u, const char* name, const void*
     float* t1 = pl.buf(NB_T1, (size_t)n * h * w * mid);
     float* t2 = pl.buf(NB_T2, (size_t)n * ho * wo * mid);
     const float* res = xraw;
-    const bool wino2 = pl.f32 && !pl.d->layerwise() && pl.d->winograd && u.w_conv2.u && wino_fits(u.w_conv2, n, h, w);
+    // (on the ROI head's 4x4 maps only with many rois: a few dozen rois leave the 16 GEMMs a handful of tiles,
+    // and the split-K direct kernel is faster)
+    const bool wino2 = pl.f32 && !pl.d->layerwise() && pl.d->winograd && u.w_conv2.u && wino_fits(u.w_conv2, n, h, w) &&
+                       (h * w > 49 || (long long)n * h * w >= 16384);
     float *wino_v = nullptr, *wino_m = nullptr;
     if (wino2) {
         const size_t tp = (size_t)wino_patches_padded(n, h, w);

@@ -41,7 +41,10 @@ def test_bench_prints_one_json_line_with_the_contract_fields():
     assert d["dtype"] == "f32"                                   # the headline is the reference's arithmetic
     assert d["value"] > 0 and abs(d["value"] - 16 / (d["ms_per_step"] / 1e3)) <= 1e-3 * d["value"]
     _check_roofline(d["roofline"])
-    assert d["roofline"]["peak"] == 157.3 and d["roofline"]["kernel"].startswith("conv_igemm")
+    assert d["roofline"]["peak"] == 157.3 and d["roofline"]["kernel"].startswith("conv_f32")
+    # definition FLOPs (every layer as a direct convolution) and the FLOPs the kernels executed
+    assert 0 < d["roofline"]["executed_gflop_per_frame"] <= 354.5 * 1.02
+    assert d["roofline"]["pipeline_executed_frac"] <= d["roofline"]["pipeline_frac"] * 1.02
     a = d["accuracy_vs_float64"]
     assert a["max_abs_score_err_vs_f64"] <= 1e-4 and a["max_box_err_px"] <= 0.5 and a["clamped_values"] == 0
     s = d["f16x3"]

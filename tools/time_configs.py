@@ -28,8 +28,11 @@ def run(det, frame, reps):
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / reps
     rows = profiling.end()
-    top = sorted(rows, key=lambda r: -r["ms"])[:6]
-    return dt * 1e3, [(r["kernel"], round(r["ms"] / reps, 3)) for r in top]
+    top = sorted(rows, key=lambda r: -r["ms"])
+    table = [{"kernel": r["kernel"], "launches": r["launches"] // reps, "ms": round(r["ms"] / reps, 3),
+              "tflops": round(r["flops"] / (r["ms"] * 1e-3) / 1e12, 1) if r["flops"] else None,
+              "gbs": round(r["bytes"] / (r["ms"] * 1e-3) / 1e9, 1)} for r in top]
+    return dt * 1e3, table
 
 
 def run_host(det, frame, reps):
@@ -43,7 +46,8 @@ def run_host(det, frame, reps):
 
 
 def main():
-    det = Detector("synthetic:0", 0)
+    precision = sys.argv[1] if len(sys.argv) > 1 else "f16x3"
+    det = Detector("synthetic:0", 0, precision=precision)
     out = {}
     out["1080p_single"] = run(det, synthetic_image(1080, 1920, seed=1), 20)
     print("1080p_single_from_host  %8.2f ms/frame (PCIe upload + detect + read-back)"
@@ -53,8 +57,8 @@ def main():
     det.reconfigure()
     out["dense_crowd_1080p"] = run(det, crowd_image(1080, 1920, seed=2), 5)
     for k, (ms, top) in out.items():
-        print("%-20s %8.2f ms/frame  %s" % (k, ms, top))
-    print(json.dumps({k: {"ms": round(v[0], 3), "top_kernels_ms": v[1]} for k, v in out.items()}))
+        print("%-20s %8.2f ms/frame  %s" % (k, ms, [(r["kernel"], r["ms"]) for r in top[:8]]))
+    print(json.dumps({"precision": precision, **{k: {"ms": round(v[0], 3), "kernels": v[1]} for k, v in out.items()}}))
 
 
 if __name__ == "__main__":
