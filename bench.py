@@ -201,6 +201,9 @@ def main():
                          "durations inside the timed region are those of an otherwise idle chip")
     ap.add_argument("--split-streams", type=int, default=2,
                     help="HIP streams of the f16x3 sub-record (its memory-bound and matrix-bound kernels overlap)")
+    ap.add_argument("--two-streams", action="store_true",
+                    help="also time the headline precision on two streams (sub-record two_streams; off by default so "
+                         "that a kernel trace of the default run holds single-stream launches of the headline kernels only)")
     ap.add_argument("--precision", default="f32", choices=["f32", "f16x3"],
                     help="arithmetic of the HEADLINE: float32 operands (the reference's, default), or the f16x3 split")
     ap.add_argument("--no-split-record", action="store_true", help="skip the f16x3 sub-record and the accuracy check")
@@ -298,7 +301,7 @@ def main():
     from facedetection_amd.pipeline import FramePipeline
 
     do_split = not args.no_split_record and args.precision == "f32"
-    n_streams = max(args.streams, args.split_streams if do_split else 1)
+    n_streams = max(args.streams, args.split_streams if do_split else 1, 2 if args.two_streams else 1)
     pipe = FramePipeline("synthetic:0", local, streams=n_streams, precision=args.precision)
     frames = make_frames(args.frames, device, seed=rank)
     B = max(1, min(args.batch, args.frames))
@@ -392,6 +395,9 @@ def main():
         return roof, table
 
     head = measure(args.precision, args.streams)
+    # the same pass with micro-batches alternating over two streams (reported beside the headline: kernels
+    # of the two streams overlap, so per-kernel durations there say nothing about a kernel's own roofline)
+    head2 = measure(args.precision, 2) if (args.two_streams and args.streams == 1 and n_streams >= 2) else None
     sub = measure("f16x3", args.split_streams) if do_split else None
 
     # hand-off (untimed): per-frame detection lists gathered in global frame order
@@ -437,6 +443,10 @@ def main():
         if roof:
             line["roofline"] = roof
             line["kernels_single_stream_step"] = table
+        if head2:
+            line["two_streams"] = {"value": round(total_frames / head2["elapsed"], 3), "unit": "frames/s",
+                                   "ms_per_step": round(1000.0 * head2["elapsed"] / args.steps, 3), "streams": 2,
+                                   "dtype": line["dtype"]}
         acc = None
         if do_split and args.check_frames > 0:
             acc = accuracy_vs_float64(pipe, frames, min(args.check_frames, args.frames))

@@ -21,3 +21,4 @@ python3 tools/pmc_summary.py $(ls $OUT/pmc_fetch/*/*counter_collection.csv | hea
 rm -rf $OUT/pmc_fetch $OUT/pmc_write $OUT/kt
 timeout -k 10 600 python3 bench.py > $OUT/bench.json 2> $OUT/bench.err
 cat $OUT/pmc_summary.txt
+timeout -k 10 600 python3 bench.py --two-streams --no-split-record --no-cpu-baseline > $OUT/bench_two_streams.json 2> $OUT/bench2.err
