@@ -109,6 +109,35 @@ def test_nms_many_row_panels_vs_c_oracle(P, n, nc):
                                   np.asarray(cboxes.nms(dets, 0.7), dtype=np.int64))
 
 
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("thr", [0.5, 0.3, 0.25, 0.7, 0.2])
+def test_nms_pairs_exactly_on_the_threshold(P, dtype, thr):
+    """Boxes on a small integer grid: IoUs are ratios of small integers, so many pairs sit exactly
+    on the threshold (1/2, 3/10, 1/4, 7/10, 1/5) or one unit of area away from it.  The kernel decides
+    pairs far from the threshold without the division; these are the pairs that must still take the
+    reference's rounded quotient, `inter / union <= thresh` in the dtype of the boxes."""
+    rng = np.random.default_rng(int(thr * 1000) + (dtype == np.float64))
+    n = 6000                                      # two row panels
+    x1 = rng.integers(0, 24, n); y1 = rng.integers(0, 24, n)
+    w = rng.integers(1, 21, n); h = rng.integers(1, 21, n)
+    dets = np.stack([x1, y1, x1 + w - 1, y1 + h - 1, rng.permutation(n) / n], axis=1).astype(dtype)
+    # how many pairs of the first 1000 boxes sit exactly on the threshold (the test must not be vacuous)
+    a = dets[:1000].astype(np.float64)
+    area = (a[:, 2] - a[:, 0] + 1) * (a[:, 3] - a[:, 1] + 1)
+    iw = np.clip(np.minimum(a[:, None, 2], a[None, :, 2]) - np.maximum(a[:, None, 0], a[None, :, 0]) + 1, 0, None)
+    ih = np.clip(np.minimum(a[:, None, 3], a[None, :, 3]) - np.maximum(a[:, None, 1], a[None, :, 1]) + 1, 0, None)
+    inter = iw * ih
+    union = area[:, None] + area[None, :] - inter
+    from fractions import Fraction
+    fr = Fraction(thr).limit_denominator(20)
+    assert int(np.sum(inter * fr.denominator == union * fr.numerator)) >= 20
+    from oracle import cboxes
+    want = cboxes.nms(dets, thr)
+    if thr == 0.5:
+        assert want == list(ob.nms(dets, thr))    # the C and the NumPy restatement agree on these as well
+    np.testing.assert_array_equal(np.asarray(P.nms(dets, thr), dtype=np.int64), np.asarray(want, dtype=np.int64))
+
+
 def test_nms_many_equal_scores(P):
     rng = np.random.default_rng(9)
     dets = rand_dets(rng, 3000, 100)
