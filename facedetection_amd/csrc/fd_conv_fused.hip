@@ -1133,7 +1133,11 @@ struct StemPoolArgs {
     unsigned plane_bytes;    // size of one plane
 };
 
-template <int PH, int PW, int BM, int OCC>
+// F32: float32 operands.  The staged image is one plane of 16-byte columns (4 floats per pixel), so the 8
+// window pixels of a kernel row are the 128 contiguous bytes of a K-step row of floats: chunk j is window
+// pixel j, and MFMA t of a part (v_mfma_f32_16x16x4_f32) multiplies channel t of pixels part * 4 .. + 3 with the
+// matching weights.  The image takes the same LDS bytes as the two half-precision planes.
+template <int PH, int PW, int BM, int OCC, bool F32>
 __global__ __launch_bounds__(256, OCC) void stem_pool_kernel(StemPoolArgs a, unsigned x_bytes, unsigned w_bytes) {
 #if defined(__HIP_DEVICE_COMPILE__)
     constexpr int BN = 64, COUT = 64;
@@ -1165,25 +1169,27 @@ __global__ __launch_bounds__(256, OCC) void stem_pool_kernel(StemPoolArgs a, uns
     // instead of one 128-byte row per patch pixel and kernel row (226 KB).  The zero columns of
     // the image stand in for the horizontal padding; rows above / below the image go out of range
     // and read zeros.
-    constexpr int IH = 2 * (CH - 1) + 7, IWC = 2 * (CW - 1) + 8;   // image rows, 8-byte columns
-    constexpr int IROW = IWC * 8;                                  // bytes per image row in LDS
+    constexpr int IH = 2 * (CH - 1) + 7, IWC = 2 * (CW - 1) + 8;   // image rows, columns (8 bytes per plane, or 16)
+    constexpr int COLB = F32 ? 16 : 8;                             // bytes per column of a plane
+    constexpr int NPL = F32 ? 1 : 2;                               // planes
+    constexpr int IROW = IWC * COLB;                               // bytes per image row in LDS
     static_assert(IROW % 16 == 0, "image rows are whole 16-byte chunks");
     constexpr int ICH = IROW / 16;                                 // chunks per row
     constexpr int IPLANE = IH * IROW;
-    constexpr int IMG_BYTES = ((2 * IPLANE + 1023) / 1024) * 1024;
+    constexpr int IMG_BYTES = ((NPL * IPLANE + 1023) / 1024) * 1024;
     constexpr int WGT_BYTES = 7 * 64 * 128;
     static_assert(IMG_BYTES + WGT_BYTES <= SMEM * 4, "LDS plan");
     char* const sbytes = reinterpret_cast<char*>(smem);
     {
         const int iy0 = 2 * oy0 - 3, ix0 = 2 * ox0;                // first image row, first column
-        constexpr int NCHUNK = 2 * IH * ICH;
+        constexpr int NCHUNK = NPL * IH * ICH;
         for (int base = wave * 64; base < NCHUNK; base += 256) {
             const int idx = base + lane;
             const int pl = idx / (IH * ICH), rem = idx - pl * (IH * ICH);
             const int r = rem / ICH, c = rem - r * ICH;
             const int iy = iy0 + r;
             const bool ok = idx < NCHUNK && (unsigned)iy < (unsigned)a.H;
-            const unsigned vo = ok ? (unsigned)(pl * a.plane_bytes) + (unsigned)(((img * a.H + iy) * a.Wpad + ix0) * 8 + c * 16) : OOB;
+            const unsigned vo = ok ? (unsigned)(pl * a.plane_bytes) + (unsigned)(((img * a.H + iy) * a.Wpad + ix0) * COLB + c * 16) : OOB;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (__attribute__((address_space(3))) void*)(sbytes + base * 16), 16, vo, 0,
                                                      0, 0);
         }
@@ -1213,7 +1219,7 @@ __global__ __launch_bounds__(256, OCC) void stem_pool_kernel(StemPoolArgs a, uns
         int row = wm * (BM / 2) + mi * 16 + frow;
         if (row >= CH * CW) row = CH * CW - 1;           // rows beyond the patch: any valid address (masked later)
         const int pr = row / CW, pc = row - pr * CW;
-        x_off[mi] = (2 * pr) * IROW + (2 * pc + 2 * fh) * 8;
+        x_off[mi] = F32 ? (2 * pr) * IROW + (2 * pc + fh) * 16 : (2 * pr) * IROW + (2 * pc + 2 * fh) * 8;
     }
     int w_off[2];
 #pragma unroll
@@ -1221,6 +1227,31 @@ __global__ __launch_bounds__(256, OCC) void stem_pool_kernel(StemPoolArgs a, uns
         w_off[part] = IMG_BYTES + (wn * (BN / 2) + frow) * 128 + (((part * 4 + fh) ^ sw) * 16);
     wait_vmcnt<0>();
     __syncthreads();
+    if constexpr (F32) {
+#pragma unroll
+        for (int kt = 0; kt < 7; ++kt)
+#pragma unroll
+            for (int part = 0; part < 2; ++part) {
+                f32x4 wv[T::AN];
+#pragma unroll
+                for (int ni = 0; ni < T::AN; ++ni)
+                    wv[ni] = *reinterpret_cast<const f32x4*>(sbytes + w_off[part] + kt * (64 * 128) + ni * 2048);
+#pragma unroll
+                for (int mh = 0; mh < T::AM; mh += 4) {
+                    f32x4 xv[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        xv[q] = *reinterpret_cast<const f32x4*>(sbytes + x_off[mh + q] + part * 64 + kt * IROW);
+#pragma unroll
+                    for (int t = 0; t < 4; ++t)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q)
+#pragma unroll
+                            for (int ni = 0; ni < T::AN; ++ni)
+                                acc[mh + q][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[ni][t], xv[q][t], acc[mh + q][ni], 0, 0, 0);
+                }
+            }
+    } else {
 #pragma unroll
     for (int kt = 0; kt < 7; ++kt) {
         // weights as the MFMA's row operand: a lane ends up with 4 consecutive channels of a
@@ -1242,6 +1273,7 @@ __global__ __launch_bounds__(256, OCC) void stem_pool_kernel(StemPoolArgs a, uns
                 acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[ni], xh, acc[mi][ni], 0, 0, 0);
             }
         }
+    }
     }
     __syncthreads();             // every wave is done with the image and the weights: the patch overlays them
 
@@ -1305,13 +1337,19 @@ __global__ __launch_bounds__(256, OCC) void stem_pool_kernel(StemPoolArgs a, uns
                 m1[j] = fmaxf(m1[j] * s1[j] + t1[j], 0.f);
             }
         }
-        f16x8 hi, lo;
-        split8(m0, m1, hi, lo, bad);
-        uint8_t* sp = a.ysplit + orow * COUT * 4 + split_offset(c);
-        *reinterpret_cast<f16x8*>(sp) = hi;
-        *reinterpret_cast<f16x8*>(sp + 64) = lo;
+        if constexpr (F32) {
+            float* ap = reinterpret_cast<float*>(a.ysplit) + orow * COUT + c;
+            *reinterpret_cast<f32x4*>(ap) = m0;
+            *reinterpret_cast<f32x4*>(ap + 4) = m1;
+        } else {
+            f16x8 hi, lo;
+            split8(m0, m1, hi, lo, bad);
+            uint8_t* sp = a.ysplit + orow * COUT * 4 + split_offset(c);
+            *reinterpret_cast<f16x8*>(sp) = hi;
+            *reinterpret_cast<f16x8*>(sp + 64) = lo;
+        }
     }
-    split_report(a.clamped, bad);
+    if constexpr (!F32) split_report(a.clamped, bad);
 #endif
 }
 
@@ -1339,14 +1377,18 @@ int stem_pool_forward(const SplitConvParams& p, const void* staged_planar, int b
     a.tiles_y = ceil_div(a.Hp, PH); a.tiles_x = ceil_div(a.Wp, PW);
     const size_t x_bytes = (size_t)batch * h * a.Wpad * 16, w_bytes = s.packed_floats() * 4;
     FD_REQUIRE(x_bytes < (1ull << 31), "stem+pool: staged batch too large for 32-bit offsets");
-    a.plane_bytes = (unsigned)(x_bytes / 2);
+    a.plane_bytes = p.f32 ? (unsigned)x_bytes : (unsigned)(x_bytes / 2);
     const long long grid = (long long)batch * a.tiles_y * a.tiles_x;
     FD_REQUIRE(grid < (1ll << 31), "stem+pool: too many tiles");
-    ProfScope scope(stream, "stem_pool", 2.0 * batch * a.Ho * a.Wo * 64.0 * 147.0,
+    ProfScope scope(stream, p.f32 ? "stem_pool_f32" : "stem_pool", 2.0 * batch * a.Ho * a.Wo * 64.0 * 147.0,
                     16.0 * batch * h * w + 4.0 * 64.0 * 224.0 +
                         256.0 * batch * a.Hp * a.Wp * ((y32 ? 1.0 : 0.0) + 1.0));
-    hipLaunchKernelGGL((stem_pool_kernel<PH, PW, STEM_BM, STEM_OCC>), dim3((unsigned)grid), dim3(256), 0, stream, a,
-                       (unsigned)x_bytes, (unsigned)w_bytes);
+    if (p.f32)
+        hipLaunchKernelGGL((stem_pool_kernel<PH, PW, STEM_BM, STEM_OCC, true>), dim3((unsigned)grid), dim3(256), 0, stream,
+                           a, (unsigned)x_bytes, (unsigned)w_bytes);
+    else
+        hipLaunchKernelGGL((stem_pool_kernel<PH, PW, STEM_BM, STEM_OCC, false>), dim3((unsigned)grid), dim3(256), 0, stream,
+                           a, (unsigned)x_bytes, (unsigned)w_bytes);
     FD_LAUNCH_CHECK();
     return FD_OK;
 }

@@ -75,6 +75,10 @@ int stage_input_split(const uint8_t* frames, int batch, int h, int w, const Inpu
 int staged_planar_width(int w);
 int stage_input_planar(const uint8_t* frames, int batch, int h, int w, const InputNorm& norm, void* y,
                        unsigned* clamped, hipStream_t stream);
+// float32 operands (p.f32): the staged image is the single float32 plane written by stage_input_padded_f32
+// (same zero columns, 16 bytes per column) and `ysplit` receives the plain float32 activated tensor.
+int stage_input_padded_f32(const uint8_t* frames, int batch, int h, int w, const InputNorm& norm, void* y,
+                           hipStream_t stream);
 int stem_pool_forward(const SplitConvParams& p, const void* staged_planar, int batch, int h, int w,
                       const float* post_scale, const float* post_shift, float* y32, void* ysplit,
                       unsigned* clamped, hipStream_t stream);

@@ -1103,6 +1103,35 @@ __global__ __launch_bounds__(256) void stage_input_planar_kernel(const uint8_t* 
     split_report(clamped, bad);
 }
 
+// The float32 form of that image: one plane [B][H][Wpad][4] floats (16 bytes per column), same zero columns.
+__global__ __launch_bounds__(256) void stage_input_padded_f32_kernel(const uint8_t* __restrict__ f, int W, int Wpad,
+                                                                    long long slots, InputNorm n, float4* __restrict__ y) {
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= slots) return;
+    const int col = (int)(t % Wpad);
+    const long long row = t / Wpad;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int x = col - 3;
+    if ((unsigned)x < (unsigned)W) {
+        const uint8_t* p = f + (row * W + x) * 3;
+        v = make_float4((float)p[0] * n.scale[0] + n.shift[0], (float)p[1] * n.scale[1] + n.shift[1],
+                        (float)p[2] * n.scale[2] + n.shift[2], 0.f);
+    }
+    y[t] = v;
+}
+
+int stage_input_padded_f32(const uint8_t* frames, int batch, int h, int w, const InputNorm& norm, void* y,
+                           hipStream_t stream) {
+    FD_REQUIRE(frames && y, "stage_input_padded_f32: NULL tensor");
+    const int wpad = staged_planar_width(w);
+    const long long slots = (long long)batch * h * wpad;
+    ProfScope scope(stream, "stage_input", 0.0, 3.0 * batch * h * (double)w + 16.0 * (double)slots);
+    hipLaunchKernelGGL(stage_input_padded_f32_kernel, dim3((unsigned)ceil_div(slots, 256)), dim3(256), 0, stream, frames,
+                       w, wpad, slots, norm, static_cast<float4*>(y));
+    FD_LAUNCH_CHECK();
+    return FD_OK;
+}
+
 int stage_input_planar(const uint8_t* frames, int batch, int h, int w, const InputNorm& norm, void* y,
                        unsigned* clamped, hipStream_t stream) {
     FD_REQUIRE(frames && y, "stage_input_planar: NULL tensor");

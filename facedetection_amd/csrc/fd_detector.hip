@@ -51,7 +51,7 @@ struct fd_detector {
     std::vector<fd::Unit> stage[4];
     fd::ConvParams rpn_conv, rpn_out;
     fd::SplitConvParams s_conv0, s_rpn_conv, s_rpn_out;
-    fd::SplitConvParams f_rpn_conv, f_rpn_out;
+    fd::SplitConvParams f_rpn_conv, f_rpn_out, f_conv0;
     fd::WinoConvParams w_rpn_conv;       // the RPN's 3x3 convolution in Winograd form (float32 precision)
     bool winograd = true;                // float32 precision: use it (environment variable FD_WINOGRAD=0: direct)
     int precision = FD_PRECISION_F16X3;
@@ -250,6 +250,8 @@ static int build(fd_detector* d, const ParamTable& t) {
     ConvShape s0 = shape(4, FILTERS[0], 7, 2, 3);
     s0.kwp = 8;
     FD_TRY(make_conv(d, w0->data_host, 3, s0, &sc, &sh, 1, &d->conv0, &d->s_conv0));
+    d->f_conv0.s = s0; d->f_conv0.w = d->conv0.w; d->f_conv0.w_inv_scale = 1.f; d->f_conv0.bias = d->conv0.bias;
+    d->f_conv0.relu = 1; d->f_conv0.f32 = true;
     int cin = FILTERS[0];
     for (int s = 0; s < 4; ++s) {
         const int cout = FILTERS[s + 1];
@@ -572,11 +574,12 @@ static int run_graph_split(Plan& pl, const uint8_t* frames, int B, int H, int W,
     // convolution output.
     const size_t planar_floats = (size_t)B * H * staged_planar_width(W) * 4;
     const bool f32 = pl.f32;                 // float32 operands: same graph, "split" tensors are plain float32
-    const bool fused_stem = !layerwise && !f32 && planar_floats * 4 < (1ull << 31);
+    const bool fused_stem = !layerwise && planar_floats * 4 < (1ull << 31);
     float* staged = pl.buf(NB_STAGED, fused_stem ? planar_floats : (size_t)B * H * W * 4);
     if (!pl.dry) {
         FD_HIP(hipMemsetAsync(d->clamped, 0, sizeof(unsigned), pl.stream));
-        if (f32) FD_TRY(stage_input(frames, B, H, W, d->norm, staged, pl.stream));
+        if (f32 && fused_stem) FD_TRY(stage_input_padded_f32(frames, B, H, W, d->norm, staged, pl.stream));
+        else if (f32) FD_TRY(stage_input(frames, B, H, W, d->norm, staged, pl.stream));
         else if (fused_stem) FD_TRY(stage_input_planar(frames, B, H, W, d->norm, staged, d->clamped, pl.stream));
         else FD_TRY(stage_input_split(frames, B, H, W, d->norm, staged, d->clamped, pl.stream));
     }
@@ -607,8 +610,8 @@ static int run_graph_split(Plan& pl, const uint8_t* frames, int B, int H, int W,
     // max pool: float32 copy only for inspection; the first unit (projection shortcut) needs act only
     if (!pl.dry) {
         if (fused_stem)
-            FD_TRY(stem_pool_forward(d->s_conv0, staged, B, H, W, d->stage[0][0].bn1_scale, d->stage[0][0].bn1_shift,
-                                     nullptr, abuf[0], d->clamped, pl.stream));
+            FD_TRY(stem_pool_forward(f32 ? d->f_conv0 : d->s_conv0, staged, B, H, W, d->stage[0][0].bn1_scale,
+                                     d->stage[0][0].bn1_shift, nullptr, abuf[0], d->clamped, pl.stream));
         else
             FD_TRY(maxpool_3x3s2_split(c0, B, h1, w1, FILTERS[0], d->stage[0][0].bn1_scale,
                                        d->stage[0][0].bn1_shift, layerwise ? xbuf[0] : nullptr, abuf[0], d->clamped,
