@@ -70,8 +70,9 @@ __global__ __launch_bounds__(256) void resize_linear_u8_kernel(const uint8_t* __
 
 // ---------------------------------------------------------------------------------
 // The same resize for 3-channel frames with the source staged through LDS.  A workgroup owns a
-// band of RZ_TY destination rows and walks it in tiles of RZ_TX pixels.  The source rectangle a
-// tile's taps touch (about RZ_TY / fy + 2 rows of RZ_TX / fx + 2 pixels) is fetched by LDS-DMA
+// band of RZ_TY destination rows and walks it in tiles of RZ_TX pixels.  For every tile the two tap
+// rows of each destination row (16 staged rows; rows between the taps of a strong reduction are never
+// touched), cut to the columns the tile's taps span (about RZ_TX / fx + 2 pixels), are fetched by LDS-DMA
 // (`buffer_load_dwordx4 ... lds`): whole aligned 16-byte chunks of every source row, consecutive
 // lanes on consecutive chunks, so each row segment is one coalesced burst and every source byte is
 // fetched once per tile instead of once per tap and channel with single-byte loads; chunks past the
@@ -94,7 +95,7 @@ __global__ __launch_bounds__(256) void resize_linear_u8_kernel(const uint8_t* __
 // a third of the rate (ablation: 110 us for loads + stores against 73 us for the loads alone).
 // Arithmetic is that of resize_linear_u8_kernel, bit for bit.
 constexpr int RZ_TX = 128, RZ_TY = 8;
-constexpr int RZ_ROUNDS = 8;          // DMA rounds of 256 chunks per tile: rectangles of up to 32 KB
+constexpr int RZ_ROUNDS = 8;          // DMA rounds of 256 chunks per tile: up to 32 KB of staged rows (2 KB per row)
 
 struct Resize3Args {
     const uint8_t* src;
@@ -173,18 +174,6 @@ __global__ __launch_bounds__(256) void resize3_lds_kernel(Resize3Args a) {
     const int cpr = pitch >> 4;                       // 16-byte chunks per staged row
     const unsigned row_bytes = (unsigned)sw * 3u;
 
-    // Which staged row and chunk lane `tid` moves in DMA round k does not depend on the tile: byte
-    // offset of the row from the rectangle's origin, and of the chunk inside the row.
-    // (24-bit multiplies throughout: full rate, and every factor is far below 2^24)
-    unsigned dma_row[RZ_ROUNDS], dma_chunk[RZ_ROUNDS];
-#pragma unroll
-    for (int k = 0; k < RZ_ROUNDS; ++k) {
-        const unsigned i = (unsigned)(k * 256 + tid);
-        const unsigned r = __umul24(i, a.inv_cpr) >> 20;
-        dma_row[k] = __umul24(r, row_bytes);
-        dma_chunk[k] = (i - __umul24(r, (unsigned)cpr)) * 16u;
-    }
-
     // column taps of tile j (one thread per destination column) into table j % 4 (j % 2 with a single
     // staging buffer), because tile j + S - 1's is written while slower waves may still be reading tile
     // j - 1's; columns past the image repeat its last one, so a table is always full
@@ -215,15 +204,26 @@ __global__ __launch_bounds__(256) void resize3_lds_kernel(Resize3Args a) {
     col_taps(0);
     if (S > 2 && ntiles > 1) col_taps(1);
     __syncthreads();
-    // taps are monotonic: the source rectangle starts at the first row tap / first column tap
-    const int r_lo = rowtab[0].x;
-    const int nrows = min(rowtab[ny - 1].y - r_lo + 1, a.max_rows);
+    // Staged rows: 2 i and 2 i + 1 hold the two tap rows of destination row i -- only the source rows the
+    // band uses are fetched (a reduction by 3.84 touches 2 rows in 3.84; a contiguous rectangle would also
+    // carry the rows in between).  Which staged row and chunk lane `tid` moves in DMA round k does not
+    // depend on the tile: byte offset of the source row in the image, and of the chunk inside the row.
+    unsigned dma_row[RZ_ROUNDS], dma_chunk[RZ_ROUNDS];
+#pragma unroll
+    for (int k = 0; k < RZ_ROUNDS; ++k) {
+        const unsigned i = (unsigned)(k * 256 + tid);
+        const unsigned r = min(__umul24(i, a.inv_cpr) >> 20, (unsigned)(2 * RZ_TY - 1));
+        const int4 e = rowtab[r >> 1];
+        dma_row[k] = (unsigned)((r & 1u) ? e.y : e.x) * row_bytes;
+        dma_chunk[k] = (i - __umul24(r, (unsigned)cpr)) * 16u;
+    }
+    const int nrows = 2 * ny;
     const int total = nrows * cpr;
     const int rounds = (total + 255) >> 8;            // DMA operations per wave and tile
     // LDS-DMA of tile j's source rectangle into buffer `slot` = j % S (its column table must be visible)
     auto issue = [&](int j, int slot) {
         const int c_lo = coltab[(j & tmask) * RZ_TX].x;
-        const unsigned origin = mis + (unsigned)(r_lo * sw + c_lo) * 3u;
+        const unsigned origin = mis + (unsigned)c_lo * 3u;
         uint8_t* buf = rz_lds + (size_t)slot * a.buf_bytes;
 #pragma unroll
         for (int k = 0; k < RZ_ROUNDS; ++k) {
@@ -240,9 +240,8 @@ __global__ __launch_bounds__(256) void resize3_lds_kernel(Resize3Args a) {
     constexpr int GX = RZ_TX / 4;
     const int ry = tid / GX, gx = (tid - ry * GX) * 4;
     const int4 rt = rowtab[ry];
-    const unsigned r0 = (unsigned)(rt.x - r_lo), r1 = (unsigned)(rt.y - r_lo);
-    const unsigned rowpos0 = __umul24(r0, (unsigned)pitch), rowpos1 = __umul24(r1, (unsigned)pitch);
-    const unsigned rowoff0 = __umul24(r0, row_bytes), rowoff1 = __umul24(r1, row_bytes);
+    const unsigned rowpos0 = __umul24((unsigned)(2 * ry), (unsigned)pitch), rowpos1 = rowpos0 + (unsigned)pitch;
+    const unsigned rowoff0 = (unsigned)rt.x * row_bytes, rowoff1 = (unsigned)rt.y * row_bytes;
     const unsigned orow = __umul24((unsigned)(dy0 + ry), (unsigned)dw);
     const unsigned bz = (unsigned)rt.z << 12, bw = (unsigned)rt.w << 12;     // row weights (<= 2^11) as 24-bit factors
 
@@ -278,7 +277,7 @@ __global__ __launch_bounds__(256) void resize3_lds_kernel(Resize3Args a) {
         const int2* ctab = coltab + (j & tmask) * RZ_TX;
         const uint8_t* buf = rz_lds + (size_t)cur * a.buf_bytes;
         const int c_lo = ctab[0].x;
-        const unsigned origin = mis + (unsigned)(r_lo * sw + c_lo) * 3u;
+        const unsigned origin = mis + (unsigned)c_lo * 3u;
         // byte position of source column c_lo inside each of the two staged rows (their alignment differs)
         const unsigned base0 = rowpos0 + ((origin + rowoff0) & 15u);
         const unsigned base1 = rowpos1 + ((origin + rowoff1) & 15u);
@@ -455,7 +454,7 @@ int fd_resize_cvt_u8(fd_ctx* ctx, const uint8_t* src, int batch, int src_h, int 
         fd::Resize3Args a;
         a.src = src; a.dst = dst; a.scale_x = scale_x; a.scale_y = scale_y;
         a.sh = src_h; a.sw = src_w; a.dh = dst_h; a.dw = dst_w;
-        a.max_rows = std::min(src_h, (int)std::ceil(fd::RZ_TY * scale_y) + 3);
+        a.max_rows = 2 * fd::RZ_TY;                              // the two tap rows of every destination row
         const int max_cols = std::min(src_w, (int)std::ceil(fd::RZ_TX * scale_x) + 3);
         a.pitch = ((max_cols * 3 + 15 + 8) + 15) / 16 * 16;     // worst lead + the taps' 8-byte window, in whole chunks
         const int cpr = a.pitch / 16;

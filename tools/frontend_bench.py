@@ -52,6 +52,23 @@ def main():
         "frames": n, "frames_per_s": round(n / t, 1), "GB_per_s": round(moved / t / 1e9, 1),
         "kernel_us": round(tk * 1e6, 2), "kernel_GB_per_s": round(moved / tk / 1e9, 1),
         "kernel_frac_of_8TBs": round(moved / tk / 8e12, 3), "library_build": _lib.lib().fd_build_id().decode()}
+    # 4K frames through the same rule (scale 1000 / 3840)
+    n4 = max(1, n // 4)
+    f4 = torch.from_numpy(np.stack([np.tile(synthetic_image(1080, 1920, seed=100 + s), (2, 2, 1)) for s in range(n4)])).cuda()
+    s4 = 1000.0 / 3840.0
+    small4 = ops.resize_bilinear(f4, s4, s4)
+    profiling.begin()
+    for _ in range(20):
+        ops.resize_bilinear(f4, s4, s4)
+    row = [r for r in profiling.end() if r["kernel"] == "resize_linear_u8"][0]
+    tk = row["ms"] * 1e-3 / row["launches"]
+    moved4 = f4.numel() + small4.numel()
+    out["resize_4k_to_%dx%d" % (small4.shape[1], small4.shape[2])] = {
+        "frames": n4, "kernel_us": round(tk * 1e6, 2), "kernel_GB_per_s": round(moved4 / tk / 1e9, 1),
+        "kernel_GB_per_s_rows_touched": round((f4.numel() * (2.0 * s4) + small4.numel()) / tk / 1e9, 1),
+        "note": "kernel_GB_per_s counts the whole source + destination; at this scale only 2 source rows in 3.84 "
+                "are tap rows, and only those are fetched (rows_touched counts them alone)"}
+    del f4, small4
     # crop hand-off: 16 boxes per frame -> 112x112 tiles
     rng = np.random.default_rng(0)
     boxes = np.zeros((16, 5), dtype=np.float64)
