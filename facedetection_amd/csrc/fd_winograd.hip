@@ -175,3 +175,37 @@ int wino_conv_forward(const WinoConvParams& p, const float* x, int batch, int h,
 }
 
 }  // namespace fd
+
+extern "C" {
+
+int fd_conv2d_winograd(fd_ctx* ctx, const float* x_nhwc, int batch, int height, int width, int cin, const float* w_oihw,
+                       int cout, const float* bias, int relu, float* y_nhwc, void* stream) {
+    FD_REQUIRE(ctx && x_nhwc && w_oihw && y_nhwc, "fd_conv2d_winograd: NULL argument");
+    FD_REQUIRE(batch > 0 && height > 0 && width > 0 && cin > 0 && cin % 32 == 0 && cout > 0 && cout % 8 == 0,
+               "fd_conv2d_winograd: cin must be a multiple of 32 and cout of 8 (got %d, %d)", cin, cout);
+    hipStream_t st = fd::as_stream(stream);
+    // weights are transformed on the host (blocking read-back: this entry point is for tests and one-off use;
+    // the detector transforms its weights once, at creation)
+    const size_t nw = (size_t)cout * cin * 9;
+    std::vector<float> host(nw), packed;
+    FD_HIP(hipStreamSynchronize(st));
+    FD_HIP(hipMemcpy(host.data(), w_oihw, nw * sizeof(float), hipMemcpyDeviceToHost));
+    fd::WinoConvParams p;
+    p.cin = cin; p.cout = cout; p.bias = bias; p.relu = relu;
+    FD_TRY(fd::wino_pack_weights(host.data(), cout, cin, nullptr, &packed, &p.cout_pad));
+    void *u = nullptr, *v = nullptr, *m = nullptr;
+    FD_TRY(fd::scratch(ctx, fd::SLOT_MISC0, packed.size() * sizeof(float), &u));
+    FD_HIP(hipMemcpyAsync(u, packed.data(), packed.size() * sizeof(float), hipMemcpyHostToDevice, st));
+    FD_HIP(hipStreamSynchronize(st));               // `packed` goes out of scope below
+    p.u = static_cast<const float*>(u);
+    FD_REQUIRE(fd::wino_fits(p, batch, height, width),
+               "fd_conv2d_winograd: problem beyond the 32-bit reach of the kernels (batch %d, %d x %d, %d -> %d)", batch,
+               height, width, cin, cout);
+    const size_t tp = (size_t)fd::wino_patches_padded(batch, height, width);
+    FD_TRY(fd::scratch(ctx, fd::SLOT_MISC1, 16 * tp * cin * sizeof(float), &v));
+    FD_TRY(fd::scratch(ctx, fd::SLOT_MISC2, 16 * tp * cout * sizeof(float), &m));
+    return fd::wino_conv_forward(p, x_nhwc, batch, height, width, static_cast<float*>(v), static_cast<float*>(m),
+                                 y_nhwc, st);
+}
+
+}  // extern "C"

@@ -69,3 +69,29 @@ def test_winograd_rpn_convolution_against_float64(monkeypatch):
             det.close()
     assert errs["0"] <= 5e-6, errs
     assert errs["1"] <= 4 * max(errs["0"], 5e-7), errs
+
+
+@pytest.mark.parametrize("b,h,w,cin,cout", [(1, 1, 1, 32, 8), (2, 5, 7, 32, 72), (3, 8, 8, 64, 64), (1, 37, 51, 96, 40),
+                                            (2, 68, 120, 256, 256)])
+@pytest.mark.parametrize("relu", [False, True])
+def test_winograd_operator_against_float64(b, h, w, cin, cout, relu):
+    """The operator alone (fd_conv2d_winograd through the C ABI) on odd and even map sizes, a single pixel,
+    channel counts that leave GEMM tiles ragged; float64 torch convolution as the reference, and the
+    direct float32 kernel next to it: the Winograd form may carry a few times its rounding noise."""
+    from facedetection_amd import ops
+    rng = np.random.default_rng(b * 1000 + h)
+    x = rng.standard_normal((b, h, w, cin)).astype(np.float32)
+    wt = (rng.standard_normal((cout, cin, 3, 3)) * np.sqrt(2.0 / (9 * cin))).astype(np.float32)
+    bias = rng.standard_normal(cout).astype(np.float32)
+    ref = torch.nn.functional.conv2d(torch.from_numpy(x).double().permute(0, 3, 1, 2), torch.from_numpy(wt).double(),
+                                     torch.from_numpy(bias).double(), padding=1)
+    if relu:
+        ref = torch.relu(ref)
+    ref = ref.permute(0, 2, 3, 1).numpy()
+    got = ops.conv2d(x, wt, stride=1, pad=1, bias=bias, relu=relu, precision="winograd")
+    direct = ops.conv2d(x, wt, stride=1, pad=1, bias=bias, relu=relu, precision="f32")
+    assert got.shape == ref.shape
+    scale = max(float(np.abs(ref).max()), 1.0)
+    e_w, e_d = float(np.abs(got - ref).max()) / scale, float(np.abs(direct - ref).max()) / scale
+    assert e_d <= 3e-6, e_d
+    assert e_w <= max(4 * e_d, 2e-6), (e_w, e_d)
