@@ -297,8 +297,8 @@ __global__ __launch_bounds__(256, 2) void conv_split_kernel(SplitKArgs a) {
 // takes 976 us with the MFMAs removed and 1141 us with the LDS-DMA removed, 1476 us as it is).
 // F32: the operands are float32 (a staged row = 32 floats) and the products run on the fp32 matrix
 // cores; loads, LDS image, pipeline and epilogue are the same code.
-template <int BM, int BN, int NS, int WAVES = 4, bool F32 = false>
-__global__ __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) void conv_split_glds_kernel(SplitKArgs a, unsigned x_bytes,
+template <int BM, int BN, int NS, int WAVES = 4, bool F32 = false, int OCC = 0>
+__global__ __launch_bounds__(WAVES * 64, OCC ? OCC : (WAVES == 4 ? 2 : 1)) void conv_split_glds_kernel(SplitKArgs a, unsigned x_bytes,
                                                                                       unsigned w_bytes) {
 #if defined(__HIP_DEVICE_COMPILE__)   // buffer-resource builtins exist in device code only; the host pass needs just the stub
     constexpr int WROWS = BM / (WAVES / 2);     // rows of the tile per wave row
@@ -478,16 +478,17 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 4 ? 2 : 1) void conv_split_gld
 #endif
 }
 
-template <int BM, int BN, int NS, int WAVES = 4, bool F32 = false>
+template <int BM, int BN, int NS, int WAVES = 4, bool F32 = false, int OCC = 0>
 static int launch_split_glds(const SplitKArgs& a, size_t x_bytes, size_t w_bytes, hipStream_t stream) {
-    static const std::string name = std::string(F32 ? "conv_f32_" : "conv_split_") + std::to_string(BM) + "x" + std::to_string(BN);
+    static const std::string name = std::string(F32 ? "conv_f32_" : "conv_split_") + std::to_string(BM) + "x" + std::to_string(BN) +
+                                    (OCC ? "_o" + std::to_string(OCC) : std::string());
     ProfScope scope(stream, name.c_str(), 2.0 * a.M * a.Cout * (double)a.K,
                     (double)a.H * a.W * (a.M / ((double)a.Ho * a.Wo)) * 4.0 * a.Cin + 4.0 * a.Cout * (double)a.K +
                         4.0 * a.M * a.Cout * ((a.res ? 1.0 : 0.0) + (a.y32 ? 1.0 : 0.0) + (a.ysplit ? 1.0 : 0.0)));
     SplitKArgs k = a;
     const int tiles_m = ceil_div(a.M, BM);
     k.tiles_n = ceil_div(a.Cout, BN);
-    hipLaunchKernelGGL((conv_split_glds_kernel<BM, BN, NS, WAVES, F32>), dim3(tiles_m * k.tiles_n * k.ksplit),
+    hipLaunchKernelGGL((conv_split_glds_kernel<BM, BN, NS, WAVES, F32, OCC>), dim3(tiles_m * k.tiles_n * k.ksplit),
                        dim3(WAVES * 64), 0, stream, k, (unsigned)x_bytes, (unsigned)w_bytes);
     FD_LAUNCH_CHECK();
     return FD_OK;
@@ -876,6 +877,14 @@ static int split_conv_dispatch(const SplitConvParams& p, const void* x_split, co
             if (t12864 >= 384) return launch_split_reg<128, 64, REG_PRE, true>(a, x_bytes, w_bytes, stream);
             return launch_split_reg<64, 64, REG_PRE, true>(a, x_bytes, w_bytes, stream);
         }
+        // K = 256 layers (8 K-steps per tile): the per-tile prologue and epilogue weigh as much as the loop, and
+        // three workgroups per CU on 128 x 64 tiles (two pipeline stages, 48 KB of LDS, 105 registers) cover
+        // them better than two on 128 x 128: 107-117 -> 125 TF on those layers, +1.6 % frames/s.  Shorter K
+        // (the layers bound by their own output traffic; also tried: 64 x 64 tiles at five workgroups per CU)
+        // and longer K measured no gain.
+        static const int shortk = getenv("FD_F32_SHORTK") ? atoi(getenv("FD_F32_SHORTK")) : 256;
+        if (a.K > 128 && a.K <= shortk && s.cout > 64 && t12864 >= 768)
+            return launch_split_glds<128, 64, 2, 4, true, 3>(a, x_bytes, w_bytes, stream);
         if (s.cout > 64 && t128 >= 384) return launch_split_glds<128, 128, 2, 4, true>(a, x_bytes, w_bytes, stream);
         if (t12864 >= 384) return launch_split_glds<128, 64, 3, 4, true>(a, x_bytes, w_bytes, stream);
         return launch_split_glds<64, 64, 4, 4, true>(a, x_bytes, w_bytes, stream);
@@ -938,6 +947,10 @@ int gemm_f32_batched(const float* a_mat, const float* w, int nb, int rows_pad, i
     a.clamped = nullptr; a.f32 = 1;
     a.wbatch_tiles = rows_pad / 128;
     a.wbatch_bytes = (unsigned)((size_t)cout_pad * k * 4);
+    // K <= 256 (the 256-channel stage): three workgroups per CU on 128 x 64 tiles, as for the K = 256 layers
+    // of split_conv_dispatch (+0.5 % frames/s)
+    static const int gemm_o3 = getenv("FD_F32_GEMM_O3") ? atoi(getenv("FD_F32_GEMM_O3")) : 1;
+    if (gemm_o3 && k <= 256) return launch_split_glds<128, 64, 2, 4, true, 3>(a, x_bytes, w_bytes, stream);
     return launch_split_glds<128, 128, 2, 4, true>(a, x_bytes, w_bytes, stream);
 }
 
