@@ -26,9 +26,13 @@ namespace fd {
 // unit), and the compute-heavy and the traffic-heavy phase of co-resident workgroups overlap.
 // LDS: [epilogue staging 18 KB | A operand 32 KB | weight chunk 16 KB]; the K loop of the 3x3
 // uses the first 48 KB as its two pipeline stages before that.
-// F32: float32 operands on the fp32 matrix cores (same LDS image: a row of a K-step is 32 floats).
+// F32: float32 operands on the fp32 matrix cores (same LDS image: a row of a K-step is 32 floats).  That
+// variant runs THREE workgroups per CU: its weight chunk shares the LDS of the epilogue staging (52 KB per
+// workgroup), so a chunk's weights are fetched after the previous chunk's epilogue instead of during it, and
+// only one set of residual registers is live (<= 168 registers); what a workgroup no longer overlaps inside
+// itself, the third workgroup covers.
 template <int BM, int MID, bool F32>
-__global__ __launch_bounds__(256, 2) void conv_tail_fused_kernel(SplitKArgs a, SplitKArgs c, unsigned x_bytes,
+__global__ __launch_bounds__(256, F32 ? 3 : 2) void conv_tail_fused_kernel(SplitKArgs a, SplitKArgs c, unsigned x_bytes,
                                                                 unsigned w_bytes, unsigned w3_bytes) {
 #if defined(__HIP_DEVICE_COMPILE__)
     static_assert(BM == 128 && MID == 64, "written for 128-pixel tiles of a 64-channel middle layer");
@@ -40,8 +44,12 @@ __global__ __launch_bounds__(256, 2) void conv_tail_fused_kernel(SplitKArgs a, S
     constexpr int CS_BYTES = 20 * 1024;                   // epilogue staging (18 KB used)
     constexpr int AIMG_BYTES = (MID / 32) * BM * 128;     // the 1x1's A operand: MID/32 K-steps of BM rows
     constexpr int WCH_BYTES = (MID / 32) * 64 * 128;      // one chunk of 64 output channels of the 1x1's weights
-    constexpr int SMEM_BYTES = CS_BYTES + AIMG_BYTES + WCH_BYTES;
-    static_assert(2 * STAGE * 4 <= SMEM_BYTES && T::EPI * 4 <= CS_BYTES && SMEM_BYTES <= 80 * 1024, "LDS plan");
+    constexpr bool SHARED_WCH = F32;                      // the weight chunk overlays the epilogue staging
+    constexpr int WCH_OFF = SHARED_WCH ? 0 : CS_BYTES + AIMG_BYTES;
+    constexpr int SMEM_BYTES = CS_BYTES + AIMG_BYTES + (SHARED_WCH ? 0 : WCH_BYTES);
+    static_assert(2 * STAGE * 4 <= SMEM_BYTES && T::EPI * 4 <= CS_BYTES && WCH_BYTES <= (SHARED_WCH ? CS_BYTES : WCH_BYTES) &&
+                      SMEM_BYTES <= (SHARED_WCH ? 53 : 80) * 1024,
+                  "LDS plan");
     __shared__ __attribute__((aligned(16))) float smem[SMEM_BYTES / 4];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -199,7 +207,7 @@ __global__ __launch_bounds__(256, 2) void conv_tail_fused_kernel(SplitKArgs a, S
     }
 
     // ---- phase 3: the 1x1 convolution, 64 output channels at a time ----
-    float* wch = smem + (CS_BYTES + AIMG_BYTES) / 4;
+    float* wch = smem + WCH_OFF / 4;
     int a3_off[MID / 32][2], b3_off[MID / 32][2];
 #pragma unroll
     for (int kk = 0; kk < MID / 32; ++kk)
@@ -207,7 +215,7 @@ __global__ __launch_bounds__(256, 2) void conv_tail_fused_kernel(SplitKArgs a, S
         for (int part = 0; part < 2; ++part) {
             const int pos = ((part * 4 + fh) ^ sw) * 16;
             a3_off[kk][part] = CS_BYTES + kk * (BM * 128) + (wm * (BM / 2) + frow) * 128 + pos;
-            b3_off[kk][part] = CS_BYTES + AIMG_BYTES + kk * (64 * 128) + (wn * 32 + frow) * 128 + pos;
+            b3_off[kk][part] = WCH_OFF + kk * (64 * 128) + (wn * 32 + frow) * 128 + pos;
         }
     // Software pipeline over the chunks: the weights and the residual values of chunk ch + 1 are
     // requested before the epilogue of chunk ch runs, so neither round trip is exposed.  vmcnt
@@ -245,14 +253,35 @@ __global__ __launch_bounds__(256, 2) void conv_tail_fused_kernel(SplitKArgs a, S
     } while (0)
 
     const int nch = c.Cout / 64;
-    f32x4 resA[E::GROUPS][E::PASSES][2], resB[E::GROUPS][E::PASSES][2];
     const LinearRows rows{tile_m * BM, c.M};
-    FD_WEIGHTS(0);
-    split_residual_prefetch<BM, BN>(c, rows, 0, wave, lane, resA);
-    __builtin_amdgcn_sched_barrier(0);
-    for (int ch = 0; ch < nch; ch += 2) {
-        FD_CHUNK(ch, resA, resB);
-        if (ch + 1 < nch) FD_CHUNK(ch + 1, resB, resA);
+    if constexpr (SHARED_WCH) {
+        f32x4 res[E::GROUPS][E::PASSES][2];
+        for (int ch = 0; ch < nch; ++ch) {
+            __syncthreads();               // the shared region is free: phase 2 / the previous epilogue are done with it
+            FD_WEIGHTS(ch);
+            split_residual_prefetch<BM, BN>(c, rows, ch, wave, lane, res);
+            __builtin_amdgcn_sched_barrier(0);
+            wait_vmcnt<RL>();              // weights of this chunk landed; its residual may fly
+            __syncthreads();
+            f32x4 acc3[T::AM][T::AN];
+#pragma unroll
+            for (int mi = 0; mi < T::AM; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < T::AN; ++ni) acc3[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kk = 0; kk < MID / 32; ++kk) f32_mma_step<BM, BN>(sbase, a3_off[kk], b3_off[kk], acc3);
+            // (the epilogue's own first barrier separates the last weight read from the staging writes)
+            split_epilogue16<BM, BN, true>(c, smem, tile_m, ch, wave, lane, acc3, res);
+        }
+    } else {
+        f32x4 resA[E::GROUPS][E::PASSES][2], resB[E::GROUPS][E::PASSES][2];
+        FD_WEIGHTS(0);
+        split_residual_prefetch<BM, BN>(c, rows, 0, wave, lane, resA);
+        __builtin_amdgcn_sched_barrier(0);
+        for (int ch = 0; ch < nch; ch += 2) {
+            FD_CHUNK(ch, resA, resB);
+            if (ch + 1 < nch) FD_CHUNK(ch + 1, resB, resA);
+        }
     }
 #undef FD_CHUNK
 #undef FD_WEIGHTS
