@@ -69,7 +69,7 @@ def pmc_traffic(kernel):
     import re
     from facedetection_amd import _lib
     build = _lib.lib().fd_build_id().decode("ascii")
-    m = re.match(r"conv_(split|f32|igemm)_(\d+)x(\d+)(_pre)?$", kernel)
+    m = re.match(r"conv_(split|f32|igemm)_(\d+)x(\d+)(_pre|_o\d)?$", kernel)
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic.json")))
     if not m or not files:
         return None, "no PMC pass covers this kernel"
@@ -79,13 +79,14 @@ def pmc_traffic(kernel):
     if doc.get("csrc_sha16") != build:
         return None, ("%s was taken on kernel set %s, the library running is %s: refresh the PMC passes"
                       % (name, doc.get("csrc_sha16", "(unrecorded)"), build))
-    family, bm, bn, pre = m.group(1), m.group(2), m.group(3), bool(m.group(4))
+    family, bm, bn, pre = m.group(1), m.group(2), m.group(3), m.group(4) == "_pre"
+    occ = m.group(4)[2:] if (m.group(4) or "").startswith("_o") else "0"    # workgroups per CU asked for (0: default)
     if family == "igemm":
         want = re.compile(r"conv_igemm_kernel<%s, %s, false>" % (bm, bn))
     elif pre:       # BatchNorm-on-load kernel: <BM, BN, mode 0, float32 operands?>
         want = re.compile(r"conv_split_reg_kernel<%s, %s, 0, %s>" % (bm, bn, "true" if family == "f32" else "false"))
-    else:           # direct-to-LDS kernel: <BM, BN, stages, waves, float32 operands?>
-        want = re.compile(r"conv_split_glds_kernel<%s, %s, \d+, \d+, %s>" % (bm, bn, "true" if family == "f32" else "false"))
+    else:           # direct-to-LDS kernel: <BM, BN, stages, waves, float32 operands?, workgroups per CU>
+        want = re.compile(r"conv_split_glds_kernel<%s, %s, \d+, \d+, %s, %s>" % (bm, bn, "true" if family == "f32" else "false", occ))
     for kname, row in doc["kernels"].items():
         if want.search(kname):
             return row["hbm_bytes_per_launch"], "HBM bytes per launch from %s (kernel set %s)" % (name, build)
