@@ -1,32 +1,41 @@
 #!/usr/bin/env python3
 """Per-layer convolution timing from a rocprofv3 kernel trace of bench.py.
 
-    python tools/conv_layer_report.py <kernel_trace.csv> [micro_batch] [f32]
+    python tools/conv_layer_report.py <kernel_trace.csv> [micro_batch] [f16x3 | f32 | layers]
 
 Takes the convolution launches of the last complete forward pass in the trace, pairs them with
-the layer list of faster_rcnn50 at 1080p (same order as the library issues them; the stem runs
-fused with the max-pool, each unit of the 64-channel stage as one kernel) and prints duration
-and achieved TFLOP/s per layer.  Use a single-stream trace (bench.py --streams 1)."""
+the launch list of faster_rcnn50 at 1080p (same order as the library issues them, see layer_list)
+and prints duration and achieved TFLOP/s (FLOPs executed) per launch.  Use a single-stream trace of
+one precision (bench.py --streams 1 --no-split-record [--precision f16x3])."""
 import csv
 import sys
 
 
-def layer_list(B, H=1080, W=1920, R=10, fused=True):
+def layer_list(B, H=1080, W=1920, R=10, mode="f16x3"):
+    """Convolution launches of one forward pass in issue order: (name, M, N, K, FLOPs executed).
+    mode "f16x3": the stem runs fused with the max-pool and each unit of the 64-channel stage is one kernel;
+    mode "f32": fused stem, the 3x3 + 1x1 tail of each 64-channel unit is one kernel, and the stride-1 3x3
+    layers from 256 channels on (and the RPN's) are one batched Winograd GEMM launch each (4/9 of the
+    direct FLOPs, rows padded to whole tiles); mode "layers": every layer its own launch."""
     layers = []
 
-    def conv(name, n, h, w, cin, cout, k, s, p):
+    def conv(name, n, h, w, cin, cout, k, s, p, wino=False):
         ho, wo = (h + 2 * p - k) // s + 1, (w + 2 * p - k) // s + 1
-        layers.append((name, n * ho * wo, cout, cin * k * k, 2.0 * n * ho * wo * cout * cin * k * k))
+        if wino:
+            t = n * ((h + 1) // 2) * ((w + 1) // 2)
+            tp = (t + 127) // 128 * 128
+            layers.append((name + "w", 16 * tp, cout, cin, 2.0 * 16 * tp * cout * cin))
+        else:
+            layers.append((name, n * ho * wo, cout, cin * k * k, 2.0 * n * ho * wo * cout * cin * k * k))
         return ho, wo
 
-    # (a trailing "f32" argument describes the float32 path, which launches every layer on its own)
     h, w = conv("conv0", B, H, W, 3, 64, 7, 2, 3)
     h, w = (h + 2 - 3) // 2 + 1, (w + 2 - 3) // 2 + 1
     F, U = [64, 256, 512, 1024, 2048], [3, 4, 6, 3]
     cin = 64
     for s in range(4):
         if s == 3:
-            conv("rpn3x3", B, h, w, 1024, 512, 3, 1, 1)
+            conv("rpn3x3", B, h, w, 1024, 512, 3, 1, 1, wino=(mode == "f32"))
             conv("rpnout", B, h, w, 512, 72, 1, 1, 0)
             n, h, w = B * R, 7, 7
         else:
@@ -38,13 +47,15 @@ def layer_list(B, H=1080, W=1920, R=10, fused=True):
             if u == 0:
                 conv(nm + "_sc", n, h, w, cin, cout, 1, st, 0)
             conv(nm + "_c1", n, h, w, cin, mid, 1, 1, 0)
-            h2, w2 = conv(nm + "_c2", n, h, w, mid, mid, 3, st, 1)
+            wino = mode == "f32" and st == 1 and mid >= 256 and (h * w > 49 or n * h * w >= 16384)
+            h2, w2 = conv(nm + "_c2", n, h, w, mid, mid, 3, st, 1, wino=wino)
             conv(nm + "_c3", n, h2, w2, mid, cout, 1, 1, 0)
-            if fused and mid == 64 and st == 1:
-                # the units of the 64-channel stage run as one fused kernel each
-                k = 4 if u == 0 else 3
+            if mid == 64 and st == 1 and mode != "layers":
+                # f16x3: whole unit in one kernel (4 layers for the projection unit); f32: conv2 + conv3
+                k = 2 if mode == "f32" else (4 if u == 0 else 3)
                 parts = [layers.pop() for _ in range(k)]
-                layers.append((nm + "_unit", parts[0][1], parts[0][2], sum(p[3] for p in parts), sum(p[4] for p in parts)))
+                layers.append((nm + ("_tail" if mode == "f32" else "_unit"), parts[0][1], parts[0][2],
+                               sum(p[3] for p in parts), sum(p[4] for p in parts)))
             h, w, cin = h2, w2, cout
     return layers
 
@@ -54,7 +65,7 @@ def main():
     B = int(sys.argv[2]) if len(sys.argv) > 2 else 8
     rows = [r for r in csv.DictReader(open(path))
             if any(t in r["Kernel_Name"] for t in ("conv_igemm", "conv_split_", "stem_pool", "conv_tail_fused", "unit_fused", "unit_proj_fused"))]
-    layers = layer_list(B, fused=not (len(sys.argv) > 3 and sys.argv[3] == "f32"))
+    layers = layer_list(B, mode=sys.argv[3] if len(sys.argv) > 3 else "f16x3")
     last = rows[-len(layers):]
     tot = totf = 0.0
     groups = {}
