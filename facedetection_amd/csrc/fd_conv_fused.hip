@@ -1271,8 +1271,10 @@ __global__ __launch_bounds__(256, OCC) void stem_pool_kernel(StemPoolArgs a, uns
 #pragma unroll
                     for (int q = 0; q < 4; ++q)
                         xv[q] = *reinterpret_cast<const f32x4*>(sbytes + x_off[mh + q] + part * 64 + kt * IROW);
+                    // element t of a chunk is channel t of a pixel; the staged image has three real channels and
+                    // a zero fourth one, whose MFMA would add nothing: it is not issued (6 instead of 8 per kernel row)
 #pragma unroll
-                    for (int t = 0; t < 4; ++t)
+                    for (int t = 0; t < 3; ++t)
 #pragma unroll
                         for (int q = 0; q < 4; ++q)
 #pragma unroll
