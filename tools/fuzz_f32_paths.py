@@ -1,0 +1,47 @@
+#!/usr/bin/env python3
+"""One-off robustness run: precision="f32" on random frame sizes and batch sizes, the kernels of an ordinary
+pass (fused stem, fused tails, Winograd layers, three-workgroup tiles) against the layer-by-layer pass of
+the same detector.  Prints the worst relative difference per tensor; exits non-zero above 3e-5.
+
+    python tools/fuzz_f32_paths.py [cases=12] [seed=0]
+"""
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from facedetection_amd.detection import Detector  # noqa: E402
+
+
+def main():
+    cases = int(sys.argv[1]) if len(sys.argv) > 1 else 12
+    rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+    lay = Detector("synthetic:0", 0, own_context=True, precision="f32")
+    new = Detector("synthetic:0", 0, own_context=True, precision="f32")
+    lay.keep_tensors(True)
+    new.keep_tensors(True, production=True)
+    worst = {}
+    try:
+        for _ in range(cases):
+            b = int(rng.integers(1, 4))
+            h, w = int(rng.integers(32, 420)), int(rng.integers(32, 700))
+            frames = rng.integers(0, 256, size=(b, h, w, 3), dtype=np.uint8)
+            lay.forward(frames)
+            new.forward(frames)
+            for name in ("stage1_unit1", "stage1_unit3", "stage2_unit4", "feat", "rpn_out"):
+                a, c = lay.tensor(name), new.tensor(name)
+                assert a.shape == c.shape, (name, a.shape, c.shape)
+                assert np.isfinite(c).all(), (name, b, h, w)
+                rel = float(np.abs(a - c).max()) / max(float(np.abs(a).max()), 1e-30)
+                worst[name] = max(worst.get(name, 0.0), rel)
+            print("%d x %3d x %3d ok" % (b, h, w), flush=True)
+    finally:
+        lay.close()
+        new.close()
+    print(worst)
+    sys.exit(0 if max(worst.values()) <= 3e-5 else 1)
+
+
+if __name__ == "__main__":
+    main()
