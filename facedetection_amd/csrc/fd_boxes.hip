@@ -592,6 +592,8 @@ __global__ __launch_bounds__(256) void proposal_decode_kernel(const float* __res
     const int seg = blockIdx.y;
     const int N = H * W * A;
     int nvalid = 0;
+    const bool vec_deltas = lay.box_chan == 1 && ((lay.box_batch | lay.box_off | lay.box_h | lay.box_w) & 3) == 0 &&
+                            (reinterpret_cast<uintptr_t>(bbox) & 15u) == 0;
 #pragma unroll 1
     for (int it = 0; it < DECODE_PER_BLOCK / 256; ++it) {
     const int idx = blockIdx.x * DECODE_PER_BLOCK + it * 256 + threadIdx.x;
@@ -609,10 +611,17 @@ __global__ __launch_bounds__(256) void proposal_decode_kernel(const float* __res
             score = ef / (eb + ef);
         }
         const long long bbase = seg * lay.box_batch + lay.box_off + h * lay.box_h + w * lay.box_w;
-        const float dx = bbox[bbase + (4 * a + 0) * lay.box_chan];
-        const float dy = bbox[bbase + (4 * a + 1) * lay.box_chan];
-        const float dw = bbox[bbase + (4 * a + 2) * lay.box_chan];
-        const float dh = bbox[bbase + (4 * a + 3) * lay.box_chan];
+        float dx, dy, dw, dh;
+        if (vec_deltas) {
+            // channels-last head: the four deltas of an anchor are 16 contiguous, aligned bytes
+            const f32x4 d = *reinterpret_cast<const f32x4*>(bbox + bbase + 4 * a);
+            dx = d[0]; dy = d[1]; dw = d[2]; dh = d[3];
+        } else {
+            dx = bbox[bbase + (4 * a + 0) * lay.box_chan];
+            dy = bbox[bbase + (4 * a + 1) * lay.box_chan];
+            dw = bbox[bbase + (4 * a + 2) * lay.box_chan];
+            dh = bbox[bbase + (4 * a + 3) * lay.box_chan];
+        }
         if (nan_flag && (isnan(score) || isnan(dx) || isnan(dy) || isnan(dw) || isnan(dh))) atomicOr(nan_flag, 1);
         const T sx = T(w * feat_stride), sy = T(h * feat_stride);
         T x1, y1, x2, y2;
@@ -626,8 +635,8 @@ __global__ __launch_bounds__(256) void proposal_decode_kernel(const float* __res
         x2 = clampT(x2, wmax); y2 = clampT(y2, hmax);
         const T lim = T(min_size * im_s);
         valid = ((x2 - x1 + T(1)) >= lim) && ((y2 - y1 + T(1)) >= lim);
-        T* ob = boxes + ((size_t)seg * N + idx) * 4;
-        ob[0] = x1; ob[1] = y1; ob[2] = x2; ob[3] = y2;
+        typedef T box_t __attribute__((ext_vector_type(4)));
+        *reinterpret_cast<box_t*>(boxes + ((size_t)seg * N + idx) * 4) = box_t{x1, y1, x2, y2};    // one 16- or 32-byte store
         scores[(size_t)seg * N + idx] = score;
         const size_t p = (size_t)seg * N + (N - 1 - idx);
         keys[p] = valid ? desc_key(score) : KEY_INVALID32;
