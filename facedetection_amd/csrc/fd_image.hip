@@ -187,7 +187,10 @@ __global__ __launch_bounds__(256) void resize3_lds_kernel(Resize3Args a) {
             const Tap2 t = linear_tap(dx, a.scale_x, sw);
             e = make_int2(t.s0, t.w0 | (t.w1 << 16));
         }
-        coltab[(j & tmask) * RZ_TX + tid] = e;
+        // entry of column dx at (dx % 4) * (RZ_TX / 4) + dx / 4: the lanes of a wave, which own consecutive
+        // 4-pixel groups, then read consecutive 8-byte entries for each of their 4 pixels (stored in column
+        // order the reads of a wave would be 32 bytes apart and hit 4 of the 32 LDS banks)
+        coltab[(j & tmask) * RZ_TX + (tid & 3) * (RZ_TX / 4) + (tid >> 2)] = e;
     };
     // row taps of the band, by the threads the column taps leave idle
     if (tid >= RZ_TX && tid - RZ_TX < RZ_TY) {
@@ -284,7 +287,7 @@ __global__ __launch_bounds__(256) void resize3_lds_kernel(Resize3Args a) {
         unsigned vout[12];
 #pragma unroll
         for (int px = 0; px < 4; ++px) {
-            const int2 ct = ctab[gx + px];
+            const int2 ct = ctab[px * GX + (gx >> 2)];
             const unsigned coff = (unsigned)(ct.x - c_lo) * 3u;
             unsigned lo[2], hi[2];                     // bytes 0..3 and 4..7 from the first tap pixel on, per row
 #pragma unroll
