@@ -41,6 +41,8 @@ GFLOP_PER_FRAME = 354.5          # algorithmic, post_nms_top_n = 10 (2 x 177.25 
 PEAK_FP32_MATRIX_TFLOPS = 157.3  # v_mfma_f32_32x32x2_f32, dense
 PEAK_F16_MATRIX_TFLOPS = 2500.0  # v_mfma_f32_16x16x32_f16, dense
 PROP = dict(pre_nms_top_n=1000, post_nms_top_n=10, nms_thresh=0.7, min_size=50)
+PMC_BATCH = 16                   # default micro-batch; the committed PMC passes are taken at it (16 frames' stage-1
+                                 # tensors are the largest the 2^31-byte buffer-addressed kernels reach)
 
 
 def make_frames(n, device, seed):
@@ -196,7 +198,7 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--frames", type=int, default=256, help="frames per step per GPU")
-    ap.add_argument("--batch", type=int, default=8, help="frames per launch sequence")
+    ap.add_argument("--batch", type=int, default=PMC_BATCH, help="frames per launch sequence")
     ap.add_argument("--streams", type=int, default=1,
                     help="HIP streams of the headline (float32) measurement; with one stream the per-launch "
                          "durations inside the timed region are those of an otherwise idle chip")
@@ -359,7 +361,7 @@ def main():
         # ALGORITHMIC FLOP/s on that path is the dense f16 MFMA peak / 3
         split = dom["kernel"].startswith("conv_split")
         peak = PEAK_F16_MATRIX_TFLOPS / 3.0 if split else PEAK_FP32_MATRIX_TFLOPS
-        traffic, note = pmc_traffic(dom["kernel"]) if B == 8 else (None, "PMC passes are taken at micro-batch 8")
+        traffic, note = pmc_traffic(dom["kernel"]) if B == PMC_BATCH else (None, "PMC passes are taken at micro-batch %d" % PMC_BATCH)
         roof = {
             "bound": "mfma", "kernel": dom["kernel"], "achieved": round(tf, 3), "peak": round(peak, 1),
             "unit": "TFLOP/s", "frac": round(tf / peak, 4), "traffic": traffic,

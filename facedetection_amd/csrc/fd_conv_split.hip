@@ -334,6 +334,7 @@ __global__ __launch_bounds__(WAVES * 64, OCC ? OCC : (WAVES == 4 ? 2 : 1)) void 
     int hi0[GA], wi0[GA];
     unsigned abase[GA];                          // byte offset of the row's window origin (+ its chunk)
     bool mval[GA];
+    const bool linear_rows = a.K == a.Cin && a.stride == 1 && a.pad == 0 && a.Ho == a.H && a.Wo == a.W;
 #pragma unroll
     for (int i = 0; i < GA; ++i) {
         const int row = (wave + WAVES * i) * 8 + lrow;              // row inside the tile
@@ -341,6 +342,13 @@ __global__ __launch_bounds__(WAVES * 64, OCC ? OCC : (WAVES == 4 ? 2 : 1)) void 
         const int m = tile_m * BM + row;
         mval[i] = m < a.M;
         const int mm = mval[i] ? m : 0;
+        if (linear_rows) {
+            // 1x1, stride 1: output row m reads input row m, no pixel coordinates (and no divisions) needed
+            hi0[i] = 0;
+            wi0[i] = 0;
+            abase[i] = (unsigned)(mm * a.Cin * 4 + chunk * 16);
+            continue;
+        }
         const int hw = a.Ho * a.Wo;
         const int img = mm / hw;
         const int rem = mm - img * hw;

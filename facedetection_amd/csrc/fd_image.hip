@@ -110,6 +110,7 @@ struct Resize3Args {
     int stages;           // staging buffers in the ring (1 to 3): stages - 1 tiles are in flight while one is computed
     int xcd_runs;         // every XCD takes a contiguous run of (frame, band) pairs
     int batch;
+    int xparts;           // a band's walk along x is cut into this many pieces, one workgroup each
 };
 
 // s_waitcnt vmcnt(n) for a wave-uniform n known only at run time (the instruction takes an immediate)
@@ -153,13 +154,20 @@ __global__ __launch_bounds__(256) void resize3_lds_kernel(Resize3Args a) {
     // two or three source rows, so every XCD takes a contiguous run of (frame, band) pairs: the shared rows
     // are then fetched from memory once instead of once per L2.
     const unsigned nbands = (unsigned)((dh + RZ_TY - 1) / RZ_TY);
-    const unsigned nwork = nbands * (unsigned)a.batch, per_xcd = (nwork + 7u) >> 3;
-    const unsigned work = a.xcd_runs ? (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3) : blockIdx.x;
-    if (work >= nwork || (a.xcd_runs && (blockIdx.x >> 3) >= per_xcd)) return;
+    const unsigned xparts = (unsigned)a.xparts;
+    const unsigned nwork = nbands * (unsigned)a.batch * xparts, per_xcd = (nwork + 7u) >> 3;
+    const unsigned unit = a.xcd_runs ? (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3) : blockIdx.x;
+    if (unit >= nwork || (a.xcd_runs && (blockIdx.x >> 3) >= per_xcd)) return;
+    const unsigned work = unit / xparts, part = unit - work * xparts;
     const int b = (int)(work / nbands);
     const int dy0 = (int)(work - (unsigned)b * nbands) * RZ_TY;
     const int ny = min(RZ_TY, dh - dy0);
-    const int ntiles = (dw + RZ_TX - 1) / RZ_TX;
+    // this workgroup's tiles: j0 .. ntiles - 1 (the pieces of a band are neighbours in the launch order, so
+    // they run in the same XCD at about the same time)
+    const int tiles_all = (dw + RZ_TX - 1) / RZ_TX, per_part = (tiles_all + (int)xparts - 1) / (int)xparts;
+    const int j0 = (int)part * per_part;
+    const int ntiles = min(tiles_all, j0 + per_part);
+    if (j0 >= ntiles) return;
 
     // the image as a buffer whose base is 16-byte aligned (the bytes before the image inside its first
     // chunk belong to the same allocation)
@@ -204,8 +212,8 @@ __global__ __launch_bounds__(256) void resize3_lds_kernel(Resize3Args a) {
         }
         rowtab[tid - RZ_TX] = e;
     }
-    col_taps(0);
-    if (S > 2 && ntiles > 1) col_taps(1);
+    col_taps(j0);
+    if (S > 2 && ntiles > j0 + 1) col_taps(j0 + 1);
     __syncthreads();
     // Staged rows: 2 i and 2 i + 1 hold the two tap rows of destination row i -- only the source rows the
     // band uses are fetched (a reduction by 3.84 touches 2 rows in 3.84; a contiguous rectangle would also
@@ -236,8 +244,9 @@ __global__ __launch_bounds__(256) void resize3_lds_kernel(Resize3Args a) {
                 rs, (__attribute__((address_space(3))) void*)(buf + (size_t)(k * 256 + wave * 64) * 16), 16, vo, 0, 0, 0);
         }
     };
-    issue(0, 0);
-    if (S > 2 && ntiles > 1) issue(1, 1);
+    issue(j0, 0);
+    if (S > 2 && ntiles > j0 + 1) issue(j0 + 1, 1);
+    if (S == 1 && ntiles > j0 + 1) col_taps(j0 + 1);            // into the other table, while tile j0 is in flight
 
     // this thread's destination row and 4-pixel group inside every tile, and the staged rows of its taps
     constexpr int GX = RZ_TX / 4;
@@ -251,13 +260,13 @@ __global__ __launch_bounds__(256) void resize3_lds_kernel(Resize3Args a) {
     // a wave whose rows lie inside the band issues one store per tile when rows are 4-byte aligned
     const int st = (2 * wave < ny && a.dst_aligned) ? 1 : 0;
     int slot = 0;                                               // j % S
-    for (int j = 0; j < ntiles; ++j) {
+    for (int j = j0; j < ntiles; ++j) {
         if (S == 1) {
             // single buffer: latency is covered by the other workgroups of the CU (seven fit) instead
-            if (j > 0) {
-                col_taps(j);
+            if (j > j0) {
                 __syncthreads();                                // everyone has finished reading tile j - 1
                 issue(j, 0);
+                if (j + 1 < ntiles) col_taps(j + 1);            // its table was last read for tile j - 1
             }
         } else if (j + S - 1 < ntiles) col_taps(j + S - 1);
         // This wave's part of tile j has landed.  Vector-memory operations retire in issue order; after the
@@ -265,7 +274,7 @@ __global__ __launch_bounds__(256) void resize3_lds_kernel(Resize3Args a) {
         // store of tile j - 1, or (S = 2) the store of tile j - 1 only.  The loads of the tile ahead and the
         // youngest store may stay in flight, so no tile waits out a write round trip or the prefetch.
         // (A wave that stores byte by byte counts none of its stores: waiting longer is always safe.)
-        wait_vmcnt_upto((S > 2 && j + 1 < ntiles ? rounds : 0) + (j > 0 ? st : 0));
+        wait_vmcnt_upto((S > 2 && j + 1 < ntiles ? rounds : 0) + (j > j0 ? st : 0));
         __syncthreads();                                        // ... everyone's; the taps written above are visible
         if (S > 1 && j + S - 1 < ntiles) {                      // that buffer was last read while computing tile j - 1
             int ns = slot + S - 1;
@@ -474,14 +483,21 @@ int fd_resize_cvt_u8(fd_ctx* ctx, const uint8_t* src, int batch, int src_h, int 
         static const int env_xcd = getenv("FD_RESIZE_XCD") ? atoi(getenv("FD_RESIZE_XCD")) : 1;
         a.stages = env_stages >= 1 && env_stages <= 3 ? env_stages : 1;
         const size_t tables = (a.stages == 1 ? 2 : 4) * fd::RZ_TX * sizeof(int2) + fd::RZ_TY * sizeof(int4);
+        static const int env_xparts = getenv("FD_RESIZE_XPARTS") ? atoi(getenv("FD_RESIZE_XPARTS")) : 0;
         a.xcd_runs = env_xcd ? 1 : 0;
         a.batch = batch;
+        // A band's walk along x is cut into 1, 2, 4 or 8 pieces so that the launch has at least ~8192 workgroups
+        // (four rounds of the 2048 that are resident at a time): 64 1080p frames take 2 pieces (-2 %: a shorter
+        // tail; 4 pieces cost more in per-workgroup set-up than they gain), 16 4K frames 8 (-9 %).
+        a.xparts = 1;
+        while (a.xparts < 8 && (long long)fd::ceil_div(dst_h, fd::RZ_TY) * batch * a.xparts < 8192) a.xparts *= 2;
+        if (env_xparts >= 1 && env_xparts <= 8) a.xparts = env_xparts;
         const size_t smem = a.stages * (size_t)a.buf_bytes + tables;
         // chunk -> row by multiplication is exact for chunk indices below 2^20 / cpr and needs cpr >= 2
         if (smem <= 64 * 1024 && cpr >= 2 && chunks <= fd::RZ_ROUNDS * 256 && chunks + 256 <= (1 << 20) / cpr &&
             (size_t)dst_h * dst_w * 3 < (1ull << 31) && dst_h < (1 << 23) && dst_w < (1 << 23) &&
-            (long long)fd::ceil_div(dst_h, fd::RZ_TY) * batch < (1ll << 31) - 8) {
-            const long long nwork = (long long)fd::ceil_div(dst_h, fd::RZ_TY) * batch;
+            (long long)fd::ceil_div(dst_h, fd::RZ_TY) * batch * a.xparts < (1ll << 31) - 8) {
+            const long long nwork = (long long)fd::ceil_div(dst_h, fd::RZ_TY) * batch * a.xparts;
             dim3 grid((unsigned)((nwork + 7) / 8 * 8));
             const hipStream_t st = fd::as_stream(stream);
 #define FD_RZ(A2, REV) hipLaunchKernelGGL((fd::resize3_lds_kernel<A2, REV>), grid, dim3(256), smem, st, a)

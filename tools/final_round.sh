@@ -15,6 +15,6 @@ timeout -k 10 300 python3 tools/time_configs.py f32 > $OUT/cfg_f32.txt 2>&1
 cd /tmp && export TMPDIR=/tmp
 timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d $OUT/kt2 -- python3 $R/bench.py --frames 16 --steps 1 --warmup 1 --no-cpu-baseline --no-profile --check-frames 0 --no-split-record > $OUT/b16.json 2> $OUT/b16.err
 cd $R
-python3 tools/conv_layer_report.py $(ls $OUT/kt2/*/*kernel_trace.csv | head -1) 8 f32 > $OUT/layers_f32.txt 2>&1 || true
+python3 tools/conv_layer_report.py $(ls $OUT/kt2/*/*kernel_trace.csv | head -1) 16 f32 > $OUT/layers_f32.txt 2>&1 || true
 rm -rf $OUT/kt2
 echo final round done

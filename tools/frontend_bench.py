@@ -52,6 +52,23 @@ def main():
         "frames": n, "frames_per_s": round(n / t, 1), "GB_per_s": round(moved / t / 1e9, 1),
         "kernel_us": round(tk * 1e6, 2), "kernel_GB_per_s": round(moved / tk / 1e9, 1),
         "kernel_frac_of_8TBs": round(moved / tk / 8e12, 3), "library_build": _lib.lib().fd_build_id().decode()}
+    # what plain streaming reaches on this GPU with the same number of bytes (torch's device-to-device copy:
+    # half read, half written), as a yardstick next to the 8 TB/s of the data sheet; up to 32 frames the
+    # working set fits the 256 MB memory-side cache and both numbers are above what HBM delivers
+    half = torch.empty(moved // 2, dtype=torch.uint8, device="cuda")
+    half2 = torch.empty_like(half)
+    half2.copy_(half)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(20):
+        half2.copy_(half)
+    e1.record()
+    torch.cuda.synchronize()
+    tc = e0.elapsed_time(e1) * 1e-3 / 20
+    out["streaming_yardstick"] = {"copy_bytes": int(2 * half.numel()), "copy_GB_per_s": round(2 * half.numel() / tc / 1e9, 1)}
+    key = "resize_1080p_to_%dx%d" % (small.shape[1], small.shape[2])
+    out[key]["kernel_frac_of_copy_rate"] = round(out[key]["kernel_GB_per_s"] / out["streaming_yardstick"]["copy_GB_per_s"], 3)
+    del half, half2
     # 4K frames through the same rule (scale 1000 / 3840)
     n4 = max(1, n // 4)
     f4 = torch.from_numpy(np.stack([np.tile(synthetic_image(1080, 1920, seed=100 + s), (2, 2, 1)) for s in range(n4)])).cuda()

@@ -41,7 +41,7 @@ def main():
     from facedetection_amd import _build
     json.dump({"csrc_sha16": _build.source_id(),   # the kernel set these counters belong to (fd_build_id of the library)
                "note": "FETCH_SIZE x2 (gfx950 wide-read correction) + WRITE_SIZE, KiB -> bytes, averaged per launch; "
-                       "command: bench.py --frames 16 --steps 1 --warmup 1 --split-streams 1 (micro-batch 8, 1080p; float32 pass, then f16x3 pass)",
+                       "command: bench.py --frames 16 --steps 1 --warmup 1 --split-streams 1 (micro-batch 16, 1080p; float32 pass, then f16x3 pass)",
                "kernels": out}, open(sys.argv[3], "w"), indent=1, sort_keys=True)
     for k, v in sorted(out.items(), key=lambda kv: -kv[1]["hbm_bytes_per_launch"] * kv[1]["launches"])[:8]:
         print("%-50s %4d launches  %8.1f MB/launch" % (k[:50], v["launches"], v["hbm_bytes_per_launch"] / 1e6))
