@@ -10,6 +10,7 @@ bash tools/profile_round.sh $TAG
 cp $OUT/pmc_traffic.json $R/profiles/${TAG}_pmc_traffic.json
 bash tools/profile_round.sh $TAG
 timeout -k 10 200 python3 tools/frontend_bench.py 64 > $OUT/frontend.json 2>/dev/null
+timeout -k 10 200 python3 tools/frontend_bench.py 128 > $OUT/frontend_128.json 2>/dev/null
 timeout -k 10 300 python3 tools/time_configs.py f16x3 > $OUT/cfg_split.txt 2>&1
 timeout -k 10 300 python3 tools/time_configs.py f32 > $OUT/cfg_f32.txt 2>&1
 cd /tmp && export TMPDIR=/tmp

@@ -10,7 +10,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1]
 src, dst = os.path.join(ROOT, "gpurun_out", tag), os.path.join(ROOT, "profiles")
 for name in ("kernel_stats.csv", "bench.json", "bench_under_rocprof.json", "pmc_traffic.json", "bench_two_streams.json",
-             "frontend.json"):
+             "frontend.json", "frontend_128.json"):
     shutil.copy(os.path.join(src, name), os.path.join(dst, "%s_%s" % (tag, name)))
 shutil.copy(os.path.join(src, "layers_f32.txt"), os.path.join(dst, "%s_layers_f32.txt" % tag))
 for a, b in (("cfg_split.txt", "configs_f16x3.json"), ("cfg_f32.txt", "configs_f32.json")):
@@ -26,7 +26,8 @@ for name in ("bench.json", "bench_under_rocprof.json"):
           d["f16x3"]["roofline"]["isolated"]["frac"], "| cpu", d["cpu_baseline"]["value"])
 d = json.load(open(os.path.join(dst, "%s_bench_two_streams.json" % tag)))
 print("two streams", d["value"], d["two_streams"]["value"])
-print(open(os.path.join(dst, "%s_frontend.json" % tag)).read()[:330])
+print(open(os.path.join(dst, "%s_frontend.json" % tag)).read()[:800])
+print(open(os.path.join(dst, "%s_frontend_128.json" % tag)).read()[:500])
 for b in ("configs_f16x3.json", "configs_f32.json"):
     d = json.load(open(os.path.join(dst, "%s_%s" % (tag, b))))
     print(b, {k: v["ms"] for k, v in d.items() if isinstance(v, dict)})
