@@ -782,6 +782,53 @@ __global__ __launch_bounds__(256) void boxes_to_source_kernel(const float* __res
     out[i] = (int32_t)rint((double)dets[(size_t)(i >> 2) * 5 + (i & 3)] / scale);
 }
 
+// Frames one pass can take.  The float32 kernels address their tensors through buffer descriptors with
+// 32-bit byte offsets below 2^31; the largest tensors of a pass are the stem output, the stage-1 tensors
+// and, with many proposals per frame, the ROI head's.  The f16x3 kernels have pointer-addressed forms for
+// larger tensors and take any batch.  FD_F32_PASS_FRAMES lowers the limit (tests).
+static int frames_per_pass(const fd_detector* d, int batch, int H, int W) {
+    if (d->precision != FD_PRECISION_F32) return batch;
+    const long long h2 = (H - 1) / 2 + 1, w2 = (W - 1) / 2 + 1;      // stem (7x7, stride 2, pad 3)
+    const long long h4 = (h2 - 1) / 2 + 1, w4 = (w2 - 1) / 2 + 1;    // max-pool (3x3, stride 2, pad 1)
+    long long per_frame = std::max(h2 * w2 * FILTERS[0], h4 * w4 * FILTERS[1]) * 4;
+    per_frame = std::max(per_frame, (long long)d->prop.post_nms_top_n * POOLED * POOLED * FILTERS[4] * 4);
+    long long lim = std::max(1ll, ((1ll << 31) - 1) / per_frame);
+    if (const char* e = getenv("FD_F32_PASS_FRAMES"))
+        if (atoi(e) > 0) lim = std::min<long long>(lim, atoi(e));
+    return (int)std::min<long long>(batch, lim);
+}
+
+// status block of a call that took several passes: NaN flags OR-ed, clamp counts summed
+__global__ void status_merge_kernel(int32_t* __restrict__ acc, const int32_t* __restrict__ cur, int first) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    acc[0] = first ? cur[0] : (acc[0] | cur[0]);
+    const unsigned sum = (first ? 0u : (unsigned)acc[1]) + (unsigned)cur[1];
+    acc[1] = (int32_t)min(sum, 0x7fffffffu);
+}
+
+// forward + tail over `batch` frames in passes of at most frames_per_pass frames; a frame's result does not
+// depend on which frames share its pass
+static int detect_passes(fd_detector* d, const uint8_t* frames, int batch, int height, int width, float im_scale,
+                         float thresh, float nms_thresh, int do_round, float* dets, int32_t* n_dets, hipStream_t s) {
+    FD_REQUIRE(batch > 0 && height > 0 && width > 0, "detect: bad frame shape %d x %d x %d", batch, height, width);
+    const int per = frames_per_pass(d, batch, height, width);
+    const int R = d->prop.post_nms_top_n;
+    for (int b0 = 0; b0 < batch; b0 += per) {
+        const int nb = std::min(per, batch - b0);
+        float *r = nullptr, *c = nullptr, *b = nullptr;
+        FD_TRY(forward(d, frames + (size_t)b0 * height * width * 3, nb, height, width, im_scale, &r, &c, &b, s));
+        FD_TRY(postprocess_run(d->ctx, r, 5, c, b, nb, R, height, width, thresh, nms_thresh, do_round,
+                               dets + (size_t)b0 * R * 5, n_dets + b0, s));
+        if (per < batch) {
+            hipLaunchKernelGGL(status_merge_kernel, dim3(1), dim3(64), 0, s, d->nan_flag + 2, d->nan_flag, b0 == 0 ? 1 : 0);
+            FD_LAUNCH_CHECK();
+        }
+    }
+    if (per < batch)
+        FD_HIP(hipMemcpyAsync(d->nan_flag, d->nan_flag + 2, 2 * sizeof(int32_t), hipMemcpyDeviceToDevice, s));
+    return FD_OK;
+}
+
 }  // namespace fd
 
 // =================================================================================
@@ -857,12 +904,9 @@ int fd_forward(fd_detector* d, const uint8_t* frames, int batch, int height, int
 
 int fd_detect(fd_detector* d, const uint8_t* frames, int batch, int height, int width, float thresh,
               float nms_thresh, int do_round, float* dets, int32_t* n_dets, int32_t* nan_flag, void* stream) {
-    FD_REQUIRE(d && dets && n_dets, "fd_detect: NULL argument");
-    float *r = nullptr, *c = nullptr, *b = nullptr;
+    FD_REQUIRE(d && frames && dets && n_dets, "fd_detect: NULL argument");
     hipStream_t s = fd::as_stream(stream);
-    FD_TRY(fd::forward(d, frames, batch, height, width, 1.0f, &r, &c, &b, s));
-    FD_TRY(fd::postprocess_run(d->ctx, r, 5, c, b, batch, d->prop.post_nms_top_n, height, width, thresh, nms_thresh,
-                               do_round, dets, n_dets, s));
+    FD_TRY(fd::detect_passes(d, frames, batch, height, width, 1.0f, thresh, nms_thresh, do_round, dets, n_dets, s));
     if (nan_flag) FD_HIP(hipMemcpyAsync(nan_flag, d->nan_flag, sizeof(int32_t), hipMemcpyDeviceToDevice, s));
     return FD_OK;
 }
@@ -870,12 +914,9 @@ int fd_detect(fd_detector* d, const uint8_t* frames, int batch, int height, int 
 int fd_detect_scaled(fd_detector* d, const uint8_t* frames, int batch, int height, int width, float im_scale,
                      float thresh, float nms_thresh, float* dets, int32_t* n_dets, int32_t* boxes_src,
                      int32_t* nan_flag, void* stream) {
-    FD_REQUIRE(d && dets && n_dets && im_scale > 0.0f, "fd_detect_scaled: bad arguments");
-    float *r = nullptr, *c = nullptr, *b = nullptr;
+    FD_REQUIRE(d && frames && dets && n_dets && im_scale > 0.0f, "fd_detect_scaled: bad arguments");
     hipStream_t s = fd::as_stream(stream);
-    FD_TRY(fd::forward(d, frames, batch, height, width, im_scale, &r, &c, &b, s));
-    FD_TRY(fd::postprocess_run(d->ctx, r, 5, c, b, batch, d->prop.post_nms_top_n, height, width, thresh, nms_thresh,
-                               0, dets, n_dets, s));
+    FD_TRY(fd::detect_passes(d, frames, batch, height, width, im_scale, thresh, nms_thresh, 0, dets, n_dets, s));
     if (boxes_src) {
         const int total = batch * d->prop.post_nms_top_n * 4;
         hipLaunchKernelGGL(fd::boxes_to_source_kernel, dim3(fd::ceil_div(total, 256)), dim3(256), 0, s, dets, total,

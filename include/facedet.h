@@ -248,7 +248,11 @@ int fd_forward(fd_detector* det, const uint8_t* frames, int batch, int height, i
 /* Detector.detect_face (detection.py:33-60) for `batch` frames of one size: forward pass plus
  * the tail of fd_postprocess.  dets [batch, R, 5] float32, n_dets [batch] int32: image b has
  * n_dets[b] valid rows (x1, y1, x2, y2, score), best score first.  *nan_flag (device int32,
- * may be NULL) is non-zero if the RPN produced a NaN (the reference raises ValueError). */
+ * may be NULL) is non-zero if the RPN produced a NaN (the reference raises ValueError).
+ * With FD_PRECISION_F32 a pass takes as many frames as keep every tensor below 2^31 bytes (16 at
+ * 1080p with 10 proposals per frame); a larger batch is run as several passes inside the call
+ * (fd_detect_scaled as well), a frame's rows do not depend on it, and the status block covers all
+ * passes.  fd_forward has one pass and fails for such a batch. */
 int fd_detect(fd_detector* det, const uint8_t* frames, int batch, int height, int width, float thresh,
               float nms_thresh, int do_round, float* dets, int32_t* n_dets, int32_t* nan_flag, void* stream);
 

@@ -109,3 +109,51 @@ def test_micro_batch_beyond_31_bit_offsets_matches_default_path(params):
     for a, b in zip(dets16, dets8):
         assert a.shape == b.shape
         assert np.abs(a[:, 4] - b[:, 4]).max(initial=0) <= 1e-5 and np.abs(a[:, :4] - b[:, :4]).max(initial=0) <= 1.0
+
+
+def test_float32_call_beyond_one_pass_equals_single_frames(params, monkeypatch):
+    """A float32 call whose tensors would not fit the buffer-addressed kernels' 2^31-byte reach is run in
+    several passes by the library (here forced: at most 2 frames per pass, 5 frames -> 2 + 2 + 1); a frame's
+    detections must equal, bit for bit, what it gives alone, and the status block covers all passes."""
+    from facedetection_amd.detection import Detector
+    from facedetection_amd.synthetic import synthetic_image
+    frames = np.stack([synthetic_image(360, 640, seed=40 + s) for s in range(5)])
+    det = Detector(params, 0, precision="f32")
+    try:
+        alone = [det.detect_face(f, thresh=0.5) for f in frames]
+        monkeypatch.setenv("FD_F32_PASS_FRAMES", "2")
+        f = torch.from_numpy(frames).cuda()
+        dets, n, status = det.detect_batch_device(f, thresh=0.5)
+        torch.cuda.synchronize()
+        n = n.cpu().numpy()
+        dets = dets.cpu().numpy()
+        scaled = det.detect_scaled_batch(frames, target_size=300, max_size=500, thresh=0.5)
+        monkeypatch.delenv("FD_F32_PASS_FRAMES")
+        scaled_one_pass = det.detect_scaled_batch(frames, target_size=300, max_size=500, thresh=0.5)
+    finally:
+        det.close()
+    assert sum(len(a) for a in alone) > 0 and status.cpu().tolist() == [0, 0]
+    for i in range(5):
+        np.testing.assert_array_equal(dets[i, :n[i]], alone[i])
+    for a, b in zip(scaled[0], scaled_one_pass[0]):
+        np.testing.assert_array_equal(a, b)
+    for a, b in zip(scaled[1], scaled_one_pass[1]):
+        np.testing.assert_array_equal(a, b)
+
+
+def test_float32_call_of_18_frames_of_1080p(params):
+    """18 frames of 1080p in float32: the stage-1 tensors of more than 16 frames exceed 2^31 bytes, so the call
+    takes two passes (16 + 2); results equal those of the frames run as two calls."""
+    from facedetection_amd.detection import Detector
+    from facedetection_amd.synthetic import synthetic_image
+    base = [synthetic_image(1080, 1920, seed=300 + s) for s in range(3)]
+    frames = np.stack([np.roll(base[s % 3], 37 * s, axis=1) for s in range(18)])
+    det = Detector(params, 0, precision="f32")
+    try:
+        whole = det.detect_batch(frames, thresh=0.5)
+        parts = det.detect_batch(frames[:16], thresh=0.5) + det.detect_batch(frames[16:], thresh=0.5)
+    finally:
+        det.close()
+    assert len(whole) == 18 and sum(len(a) for a in whole) > 0
+    for a, b in zip(whole, parts):
+        np.testing.assert_array_equal(a, b)
