@@ -92,6 +92,10 @@ SIGNATURES = {
     "fd_forward": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_float, vp, vp, vp, vp]),
     "fd_detect": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_int, vp, vp, vp, vp]),
     "fd_detector_status": (C.c_int, [vp, vp, vp]),
+    "fd_detect_graph_create": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, C.c_int, vp,
+                                         vp, vp, vp, C.POINTER(vp)]),
+    "fd_detect_graph_launch": (C.c_int, [vp, vp]),
+    "fd_detect_graph_destroy": (None, [vp]),
     "fd_detector_keep_tensors": (C.c_int, [vp, C.c_int]),
     "fd_detector_tensor": (C.c_int, [vp, C.c_char_p, vp, C.c_int64, C.POINTER(C.c_int64), vp]),
 }

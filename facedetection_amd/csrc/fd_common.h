@@ -84,6 +84,8 @@ struct fd_ctx {
     std::vector<fd::Buf> parked;       // replaced allocations that queued kernels may still use
     size_t parked_bytes = 0;
     int64_t bytes = 0;
+    uint64_t epoch = 0;                // counts replaced allocations: device addresses recorded earlier (a captured
+                                       // graph's kernel arguments) are stale once it has moved
 };
 
 namespace fd {

@@ -927,6 +927,106 @@ int fd_detect_scaled(fd_detector* d, const uint8_t* frames, int batch, int heigh
     return FD_OK;
 }
 
+// ---------------------------------------------------------------------------------
+// A detection call recorded once and replayed: the ~70-150 launches of a pass become one graph launch, which
+// takes the host's launch cost and the gaps between short kernels out of a single frame's latency.
+struct fd_detect_graph {
+    fd_detector* det = nullptr;
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+    hipStream_t capture_stream = nullptr;
+    uint64_t epoch = 0;
+};
+
+static void graph_release(fd_detect_graph* g) {
+    if (!g) return;
+    if (g->exec) (void)hipGraphExecDestroy(g->exec);
+    if (g->graph) (void)hipGraphDestroy(g->graph);
+    if (g->capture_stream) (void)hipStreamDestroy(g->capture_stream);
+    delete g;
+}
+
+int fd_detect_graph_create(fd_detector* d, const uint8_t* frames, int batch, int height, int width, float im_scale,
+                           float thresh, float nms_thresh, int do_round, float* dets, int32_t* n_dets,
+                           int32_t* boxes_src, int32_t* status, fd_detect_graph** out) {
+    FD_REQUIRE(d && frames && dets && n_dets && out && im_scale > 0.0f, "fd_detect_graph_create: bad arguments");
+    FD_REQUIRE(!fd::prof_active(), "fd_detect_graph_create: not while a profiling session is open");
+    FD_REQUIRE(d->keep_mode == 0, "fd_detect_graph_create: not while intermediate tensors are kept");
+    FD_HIP(hipSetDevice(d->ctx->device));
+    fd_detect_graph* g = new fd_detect_graph();
+    g->det = d;
+    if (hipStreamCreateWithFlags(&g->capture_stream, hipStreamNonBlocking) != hipSuccess) {
+        graph_release(g);
+        fd::set_error("fd_detect_graph_create: no stream");
+        return FD_ERR_HIP;
+    }
+    hipStream_t s = g->capture_stream;
+    auto body = [&]() -> int {
+        FD_TRY(fd::detect_passes(d, frames, batch, height, width, im_scale, thresh, nms_thresh, do_round, dets, n_dets, s));
+        if (boxes_src) {
+            const int total = batch * d->prop.post_nms_top_n * 4;
+            hipLaunchKernelGGL(fd::boxes_to_source_kernel, dim3(fd::ceil_div(total, 256)), dim3(256), 0, s, dets, total,
+                               (double)im_scale, boxes_src);
+            FD_LAUNCH_CHECK();
+        }
+        if (status) FD_HIP(hipMemcpyAsync(status, d->nan_flag, 2 * sizeof(int32_t), hipMemcpyDeviceToDevice, s));
+        return FD_OK;
+    };
+    // an ordinary call first: every activation and scratch buffer reaches the size this shape needs, so the
+    // recorded call allocates nothing (an allocation would fail the capture) and records final addresses
+    int rc = body();
+    if (rc == FD_OK && hipStreamSynchronize(s) != hipSuccess) {
+        fd::set_error("fd_detect_graph_create: the warm-up call failed");
+        rc = FD_ERR_HIP;
+    }
+    if (rc != FD_OK) {
+        graph_release(g);
+        return rc;
+    }
+    const uint64_t epoch0 = d->ctx->epoch;
+    if (hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) != hipSuccess) {
+        graph_release(g);
+        fd::set_error("fd_detect_graph_create: hipStreamBeginCapture failed");
+        return FD_ERR_HIP;
+    }
+    rc = body();
+    const hipError_t e = hipStreamEndCapture(s, &g->graph);      // also ends a capture that a failed call broke
+    if (rc != FD_OK || e != hipSuccess || !g->graph || d->ctx->epoch != epoch0) {
+        if (rc == FD_OK)
+            fd::set_error("fd_detect_graph_create: capture failed (%s)",
+                          e != hipSuccess ? hipGetErrorString(e) : "a buffer was re-allocated while recording");
+        (void)hipGetLastError();
+        graph_release(g);
+        return rc != FD_OK ? rc : FD_ERR_HIP;
+    }
+    const hipError_t ei = hipGraphInstantiate(&g->exec, g->graph, nullptr, nullptr, 0);
+    if (ei != hipSuccess) {
+        fd::set_error("fd_detect_graph_create: hipGraphInstantiate failed: %s", hipGetErrorString(ei));
+        graph_release(g);
+        return FD_ERR_HIP;
+    }
+    g->epoch = epoch0;
+    *out = g;
+    return FD_OK;
+}
+
+int fd_detect_graph_launch(fd_detect_graph* g, void* stream) {
+    FD_REQUIRE(g && g->exec, "fd_detect_graph_launch: NULL graph");
+    FD_REQUIRE(g->epoch == g->det->ctx->epoch,
+               "fd_detect_graph_launch: the library's buffers were re-allocated after this call was recorded "
+               "(a larger shape ran since): record it again");
+    FD_HIP(hipSetDevice(g->det->ctx->device));
+    FD_HIP(hipGraphLaunch(g->exec, fd::as_stream(stream)));
+    return FD_OK;
+}
+
+void fd_detect_graph_destroy(fd_detect_graph* g) {
+    if (!g) return;
+    (void)hipSetDevice(g->det->ctx->device);
+    (void)hipDeviceSynchronize();
+    graph_release(g);
+}
+
 int fd_detector_status(fd_detector* d, int32_t* status, void* stream) {
     FD_REQUIRE(d && status, "fd_detector_status: NULL argument");
     FD_HIP(hipMemcpyAsync(status, d->nan_flag, 2 * sizeof(int32_t), hipMemcpyDeviceToDevice, fd::as_stream(stream)));

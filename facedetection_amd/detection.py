@@ -111,6 +111,8 @@ class Detector:
         _lib.check(self._lib.fd_detector_set_proposal(self._h, C.byref(self._cfg)))
 
     def close(self):
+        for rec in self.__dict__.pop("_recorded", {}).values():
+            rec.close()
         if getattr(self, "_h", None):
             self._lib.fd_detector_destroy(self._h)
             self._h = None
@@ -263,6 +265,32 @@ class Detector:
         """detection.py:33-60: one HWC uint8 frame -> float32 [N,5]."""
         return self.detect_batch(img_np, nms_thresh, thresh, True)[0]
 
+    def record(self, batch, height, width, nms_thresh=0.3, thresh=0.8, do_round=True):
+        """The ``detect_batch`` call for frames of this shape recorded as a HIP graph: a ``RecordedDetect``
+        whose ``launch`` replays the whole pass with one launch (a single 1080p frame: about 70 kernel
+        launches less on the host and no gaps between the short kernels).  It keeps the precision and
+        proposal settings the detector has now."""
+        return RecordedDetect(self, batch, height, width, nms_thresh, thresh, do_round)
+
+    def detect_face_replayed(self, img_np, nms_thresh=0.3, thresh=0.8):
+        """``detect_face`` through a recorded pass (made on first use for each frame size and setting;
+        same results).  For loops over frames of one size, e.g. a video."""
+        a = np.asarray(img_np)
+        key = (a.shape[0], a.shape[1], float(nms_thresh), float(thresh), self.precision)
+        cache = self.__dict__.setdefault("_recorded", {})
+        for attempt in (0, 1):
+            rec = cache.get(key)
+            if rec is None or rec.stale:
+                if rec is not None:
+                    rec.close()
+                rec = cache[key] = self.record(1, a.shape[0], a.shape[1], nms_thresh, thresh, True)
+            try:
+                return rec.detect(a[None])[0]
+            except _lib.FaceDetError:
+                # a larger shape ran since the recording and moved the library's buffers: record again, once
+                if attempt or not rec.stale:
+                    raise
+
     def detect(self, img_np, nms_thresh=0.3, thresh=0.8):
         """(boxes_and_scores [N,5], landmarks [N,0]).  The reference model predicts no
         landmarks, so the second array is always empty; it is there for callers that
@@ -286,6 +314,70 @@ class Detector:
             _lib.check(self._lib.fd_detector_tensor(self._h, name.encode("ascii"), runtime.ptr(out), out.numel(),
                                                     dims, runtime.stream_ptr(self.device)))
             return out.cpu().numpy()
+
+
+class RecordedDetect:
+    """One ``fd_detect`` call recorded as a HIP graph (``fd_detect_graph_create``) with fixed device buffers:
+    ``frames`` uint8 [B,H,W,3] is the input the replay reads, ``dets`` [B,R,5], ``n`` [B] and ``status`` [2]
+    are what it writes.  ``launch`` replays on the current stream (asynchronous); ``detect`` is the host-level
+    call with the status check of ``Detector.detect_batch``.  No counterpart in the reference."""
+
+    def __init__(self, det, batch, height, width, nms_thresh, thresh, do_round):
+        self._det, self._lib, self.device = det, det._lib, det.device
+        self._args = (float(nms_thresh), float(thresh), bool(do_round))
+        with torch.cuda.device(self.device):
+            R = det.rois_per_image
+            self.frames = torch.zeros((batch, height, width, 3), dtype=torch.uint8, device="cuda:%d" % self.device)
+            self.dets = torch.zeros((batch, R, 5), dtype=torch.float32, device=self.frames.device)
+            self.n = torch.zeros((batch,), dtype=torch.int32, device=self.frames.device)
+            self.status = torch.zeros((2,), dtype=torch.int32, device=self.frames.device)
+            torch.cuda.current_stream().synchronize()          # the recording runs on a stream of its own
+            handle = C.c_void_p()
+            _lib.check(self._lib.fd_detect_graph_create(det._h, runtime.ptr(self.frames), batch, height, width, 1.0,
+                                                        float(thresh), float(nms_thresh), 1 if do_round else 0,
+                                                        runtime.ptr(self.dets), runtime.ptr(self.n), None,
+                                                        runtime.ptr(self.status), C.byref(handle)))
+            self._h = handle
+        self.stale = False
+
+    def launch(self, frames=None):
+        """Replays the pass on the current stream; ``frames`` (host array or tensor of the recorded shape) is
+        copied into the input buffer first.  Returns the device tensors (dets, n, status)."""
+        with torch.cuda.device(self.device):
+            if frames is not None:
+                t = frames if isinstance(frames, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(frames))
+                if tuple(t.shape) != tuple(self.frames.shape) or t.dtype != torch.uint8:
+                    raise ValueError("expected uint8 frames of shape %s" % (tuple(self.frames.shape),))
+                self.frames.copy_(t, non_blocking=True)
+            try:
+                _lib.check(self._lib.fd_detect_graph_launch(self._h, runtime.stream_ptr(self.device)))
+            except _lib.FaceDetError:
+                self.stale = True
+                raise
+        return self.dets, self.n, self.status
+
+    def detect(self, frames):
+        """List of float32 [n_i,5] arrays like ``Detector.detect_batch`` (falls back to the ordinary float32
+        call when the f16x3 pass had to clamp, as that does)."""
+        det = self._det
+        with torch.cuda.device(self.device):
+            dets, n, status = self.launch(frames)
+            if det._check_status(status):
+                nms_thresh, thresh, do_round = self._args
+                return det._in_f32(lambda: det.detect_batch(frames, nms_thresh, thresh, do_round))
+            n_host, dets_host = n.cpu().numpy(), dets.cpu().numpy()
+            return [dets_host[b, :n_host[b]].copy() for b in range(dets_host.shape[0])]
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.fd_detect_graph_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def resize(im, target_size, max_size):

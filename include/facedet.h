@@ -280,6 +280,25 @@ int fd_detect_scaled(fd_detector* det, const uint8_t* frames, int batch, int hei
                      float thresh, float nms_thresh, float* dets, int32_t* n_dets, int32_t* boxes_src,
                      int32_t* nan_flag, void* stream);
 
+/* No counterpart in the reference (its executor launches operator by operator): one detection call
+ * recorded as a HIP graph and replayed, for callers that run the same frame shape again and again
+ * (a video loop, one frame at a time) and want the host's launch cost and the gaps between the
+ * pass's short kernels out of the latency.  fd_detect_graph_create runs the call once in the
+ * ordinary way (all buffers reach their size), then records it: fd_detect when im_scale == 1 and
+ * boxes_src == NULL, fd_detect_scaled with do_round = 0 otherwise; `status` (device int32 [2],
+ * may be NULL) receives the status block of fd_detector_status.  All pointers are fixed by the
+ * recording: a replay reads `frames` and writes `dets`, `n_dets`, `boxes_src`, `status` at the
+ * addresses given here, with the precision and proposal settings the detector had then.
+ * fd_detect_graph_launch replays on `stream`; it fails (and nothing is launched) if the library
+ * re-allocated a buffer since the recording (a larger shape ran on the same context): record again.
+ * Replays and other calls on the same detector or context must not overlap, as for any two calls. */
+typedef struct fd_detect_graph fd_detect_graph;
+int fd_detect_graph_create(fd_detector* det, const uint8_t* frames, int batch, int height, int width, float im_scale,
+                           float thresh, float nms_thresh, int do_round, float* dets, int32_t* n_dets,
+                           int32_t* boxes_src, int32_t* status, fd_detect_graph** out);
+int fd_detect_graph_launch(fd_detect_graph* graph, void* stream);
+void fd_detect_graph_destroy(fd_detect_graph* graph);
+
 /* Status of the LAST forward pass of this detector, copied to status [2] (device int32) on `stream`
  * (the stream the pass was issued on):
  *   status[0]  non-zero if the proposal stage met a NaN in its scores or deltas -- where the reference

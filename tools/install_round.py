@@ -30,4 +30,4 @@ print(open(os.path.join(dst, "%s_frontend.json" % tag)).read()[:800])
 print(open(os.path.join(dst, "%s_frontend_128.json" % tag)).read()[:500])
 for b in ("configs_f16x3.json", "configs_f32.json"):
     d = json.load(open(os.path.join(dst, "%s_%s" % (tag, b))))
-    print(b, {k: v["ms"] for k, v in d.items() if isinstance(v, dict)})
+    print(b, {k: (v["ms"], v.get("ms_without_event_brackets"), v.get("ms_recorded_pass")) for k, v in d.items() if isinstance(v, dict)})
