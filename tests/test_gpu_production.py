@@ -168,3 +168,26 @@ def test_pipeline_of_32_frames_equals_frame_by_frame_detection(params, precision
         assert got[i].shape == ref.shape
         assert np.abs(got[i][:, 4] - ref[:, 4]).max(initial=0) <= 1e-4
         assert np.abs(got[i][:, :4] - ref[:, :4]).max(initial=0) <= 1.0
+
+
+@pytest.mark.parametrize("precision,streams", [("f32", 1), ("f16x3", 2)])
+def test_benchmark_batch_of_256_frames_equals_frame_by_frame_detection(params, precision, streams):
+    """BASELINE configuration 3 at its own size and in the benchmark's own arrangement: 256 frames of 1080p
+    in micro-batches of 16 (float32 on one stream, f16x3 on two) against Detector.detect_face on every one
+    of the 256 frames alone, bit for bit -- a frame's rows depend neither on its micro-batch nor on the stream."""
+    from facedetection_amd.detection import Detector
+    from facedetection_amd.pipeline import FramePipeline
+    frames = _frames_1080p(256)
+    pipe = FramePipeline(params, 0, streams=streams, precision=precision)
+    try:
+        got = pipe.detect(frames, micro_batch=16)
+    finally:
+        pipe.close()
+    det = Detector(params, 0, precision=precision)
+    try:
+        single = [det.detect_face(frames[i]) for i in range(256)]
+    finally:
+        det.close()
+    assert len(got) == 256 and sum(len(g) for g in got) > 256
+    for i in range(256):
+        np.testing.assert_array_equal(got[i], single[i], err_msg="frame %d" % i)
