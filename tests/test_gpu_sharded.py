@@ -1,5 +1,5 @@
-"""The sharded path end to end on real detections: three processes share the one GPU of the test box,
-each runs its own detector on the frames i with i mod 3 == rank (the reference's process-per-GPU scheme,
+"""The sharded path end to end on real detections: three (or, on 4K frames, two) processes share the one GPU of
+the test box, each runs its own detector on the frames i with i mod world == rank (the reference's process-per-GPU scheme,
 code/data_processing/ProcessVideo.py:92-114, with frames instead of videos as the unit), the
 variable-length detection lists are all-gathered (gloo here: RCCL does not accept several ranks on one
 device; the collective calls are the same) and rank 0's gathered lists must equal, frame by frame and
@@ -13,7 +13,15 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 
-N_FRAMES, WORLD, H, W = 8, 3, 360, 640          # shards of 3, 3 and 2 frames
+CASES = {"small": (8, 3, 360, 640),              # shards of 3, 3 and 2 frames
+         "4k": (5, 2, 2160, 3840)}               # BASELINE configuration 4's frame size: shards of 3 and 2 frames
+
+
+def _frame(i, h, w):
+    from facedetection_amd.synthetic import synthetic_image
+    if (h, w) == (2160, 3840):
+        return np.tile(synthetic_image(1080, 1920, seed=i), (2, 2, 1))
+    return synthetic_image(h, w, seed=i)
 
 
 def _free_port():
@@ -24,12 +32,12 @@ def _free_port():
     return port
 
 
-def _worker(rank, world, port, out_dir):
+def _worker(rank, world, port, out_dir, case):
     import torch
     import torch.distributed as dist
     from facedetection_amd.detection import Detector
     from facedetection_amd.parallel import gather_detections, shard_indices
-    from facedetection_amd.synthetic import synthetic_image
+    N_FRAMES, _, H, W = CASES[case]
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -37,7 +45,7 @@ def _worker(rank, world, port, out_dir):
         mine = shard_indices(N_FRAMES, rank, world)
         det = Detector("synthetic:0", 0)
         try:
-            frames = torch.from_numpy(np.stack([synthetic_image(H, W, seed=i) for i in mine])).cuda()
+            frames = torch.from_numpy(np.stack([_frame(i, H, W) for i in mine])).cuda()
             dets, counts, status = det.detect_batch_device(frames, thresh=0.5)
             torch.cuda.synchronize()
             assert int(status[0].item()) == 0
@@ -52,15 +60,16 @@ def _worker(rank, world, port, out_dir):
         dist.destroy_process_group()
 
 
-def test_three_processes_on_one_gpu_gather_what_one_process_detects(tmp_path):
+@pytest.mark.parametrize("case", ["small", "4k"])
+def test_processes_sharing_one_gpu_gather_what_one_process_detects(tmp_path, case):
     import torch.multiprocessing as mp
     from facedetection_amd.detection import Detector
     from facedetection_amd.parallel import feed_tracker
-    from facedetection_amd.synthetic import synthetic_image
     from facedetection_amd.tracking.sort import Sort
+    N_FRAMES, WORLD, H, W = CASES[case]
     port = _free_port()
     ctx = mp.get_context("spawn")                 # fresh processes: nothing inherited from this one's GPU state
-    procs = [ctx.Process(target=_worker, args=(r, WORLD, port, str(tmp_path))) for r in range(WORLD)]
+    procs = [ctx.Process(target=_worker, args=(r, WORLD, port, str(tmp_path), case)) for r in range(WORLD)]
     for p in procs:
         p.start()
     for p in procs:
@@ -71,7 +80,7 @@ def test_three_processes_on_one_gpu_gather_what_one_process_detects(tmp_path):
     gathered = np.split(rows, np.cumsum(lens)[:-1])
     det = Detector("synthetic:0", 0)
     try:
-        alone = [det.detect_face(synthetic_image(H, W, seed=i), thresh=0.5) for i in range(N_FRAMES)]
+        alone = [det.detect_face(_frame(i, H, W), thresh=0.5) for i in range(N_FRAMES)]
     finally:
         det.close()
     assert len(gathered) == N_FRAMES and sum(len(a) for a in alone) > 0
