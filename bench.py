@@ -383,8 +383,8 @@ def main():
         roof["pipeline_executed_tflops"] = round(executed * fps / 1e3, 3)
         roof["pipeline_executed_frac"] = round(executed * fps / 1e3 / peak, 4)
         roof["flop_note"] = ("pipeline_tflops = %.1f GFLOP per frame (every layer as a direct convolution) x frames/s; "
-                             "pipeline_executed_* = FLOPs the kernels executed (Winograd layers at 4/9, GEMM row "
-                             "padding included)" % GFLOP_PER_FRAME)
+                             "pipeline_executed_* = FLOPs the kernels executed (Winograd F(4x4,3x3) layers at 1/4 of "
+                             "the direct form's, GEMM row padding included)" % GFLOP_PER_FRAME)
         iso = [r for r in iso_rows if r["kernel"] == dom["kernel"]][0]
         itf = iso["flops"] / (iso["ms"] * 1e-3) / 1e12
         roof["isolated"] = {

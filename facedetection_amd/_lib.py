@@ -84,7 +84,7 @@ SIGNATURES = {
                             vp, vp, vp, C.c_int, vp, vp, vp]),
     "fd_conv2d_f16x3": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_int,
                                   C.c_int, vp, vp, vp, C.c_int, vp, vp, vp]),
-    "fd_conv2d_winograd": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int, vp, C.c_int, vp, vp]),
+    "fd_conv2d_winograd": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int, vp, C.c_int, C.c_int, vp, vp]),
     "fd_detector_create": (C.c_int, [vp, C.POINTER(Param), C.c_int, C.POINTER(ProposalCfg), C.POINTER(vp)]),
     "fd_detector_destroy": (None, [vp]),
     "fd_detector_set_precision": (C.c_int, [vp, C.c_int]),

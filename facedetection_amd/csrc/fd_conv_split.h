@@ -83,22 +83,23 @@ int stem_pool_forward(const SplitConvParams& p, const void* staged_planar, int b
                       const float* post_scale, const float* post_shift, float* y32, void* ysplit,
                       unsigned* clamped, hipStream_t stream);
 
-// 3x3 stride-1 pad-1 convolution by Winograd F(2x2, 3x3) in float32 (fd_winograd.hip).
+// 3x3 stride-1 pad-1 convolution by Winograd F(2x2, 3x3) or F(4x4, 3x3) in float32 (fd_winograd.hip).
 struct WinoConvParams {
     int cin = 0, cout = 0, cout_pad = 0;
-    const float* u = nullptr;      // transformed weights [16][cout_pad][cin] (device)
+    int tile = 2;                  // outputs per patch and direction: 2 (4x4 patches, 16 GEMMs) or 4 (6x6 patches, 36 GEMMs)
+    const float* u = nullptr;      // transformed weights [(tile + 2)^2][cout_pad][cin] (device)
     const float* bias = nullptr;   // [cout] or NULL
     int relu = 0;
 };
 // host: OIHW weights -> the transformed layout above (float32 values computed in double)
-int wino_pack_weights(const float* w_oihw, int cout, int cin, const float* out_scale, std::vector<float>* packed,
+int wino_pack_weights(const float* w_oihw, int cout, int cin, const float* out_scale, int tile, std::vector<float>* packed,
                       int* cout_pad);
-// number of 2x2-output patches of a batch, rounded up to whole 128-row GEMM tiles
-long long wino_patches_padded(int batch, int h, int w);
+// number of tile x tile output patches of a batch, rounded up to whole 128-row GEMM tiles
+long long wino_patches_padded(int batch, int h, int w, int tile);
 // whether the 32-bit offsets of the kernels reach every tensor of this problem
 bool wino_fits(const WinoConvParams& p, int batch, int h, int w);
 // x [B][H][W][cin] float32 -> y [B][H][W][cout] float32 (+ bias, ReLU).  Workspaces: v_ws holds
-// 16 * wino_patches_padded * cin floats, m_ws 16 * wino_patches_padded * cout floats.
+// (tile + 2)^2 * wino_patches_padded * cin floats, m_ws (tile + 2)^2 * wino_patches_padded * cout floats.
 int wino_conv_forward(const WinoConvParams& p, const float* x, int batch, int h, int w, float* v_ws, float* m_ws,
                       float* y, hipStream_t stream);
 // nb independent float32 GEMMs in one launch on the 128 x 128 direct-to-LDS kernel:

@@ -53,7 +53,8 @@ struct fd_detector {
     fd::SplitConvParams s_conv0, s_rpn_conv, s_rpn_out;
     fd::SplitConvParams f_rpn_conv, f_rpn_out, f_conv0;
     fd::WinoConvParams w_rpn_conv;       // the RPN's 3x3 convolution in Winograd form (float32 precision)
-    bool winograd = true;                // float32 precision: use it (environment variable FD_WINOGRAD=0: direct)
+    int winograd = 4;                    // float32 precision: Winograd tile of the long-K 3x3 layers, 4 = F(4x4,3x3),
+                                         // 2 = F(2x2,3x3), 0 = direct (environment variable FD_WINOGRAD)
     int precision = FD_PRECISION_F16X3;
     const float *bn1_scale = nullptr, *bn1_shift = nullptr;
     const float *w_cls = nullptr, *b_cls = nullptr, *w_box = nullptr, *b_box = nullptr;
@@ -215,16 +216,20 @@ static int build_unit(fd_detector* d, const ParamTable& t, const std::string& na
     u->bn1_shift = pre_h;
     FD_TRY(make_conv(d, w2->data_host, mid, shape(mid, mid, 3, stride, 1), &s3, &h3, 1, &u->conv2, &u->s_conv2, &u->f_conv2));
     FD_TRY(make_conv(d, w3->data_host, mid, shape(mid, cout, 1, 1, 0), nullptr, nullptr, 0, &u->conv3, &u->s_conv3, &u->f_conv3));
-    // Winograd form of the 3x3 where it pays: from 256 channels on the 16 GEMMs are long enough to run near
-    // the matrix peak and the transforms (4x the tensor size each way) cost less than the multiplies saved
-    // (the 256-channel stage and the stride-1 units of the ROI head)
-    if (stride == 1 && mid >= 256) {
+    // Winograd form of the 3x3 where it pays.  With F(4x4,3x3) (a quarter of the multiplies, Winograd-domain
+    // tensors 2.25x the plain ones) that is from 128 channels on: the 128- and 256-channel stages and the
+    // stride-1 units of the ROI head (1080p, float32: 376 -> 413 frames/s with the 256-channel stage and the RPN,
+    // 427 with the 128-channel stage as well); with F(2x2,3x3) (4/9 of the multiplies, tensors 4x) the
+    // 128-channel stage would lose.  At 64 channels the GEMMs are two K-steps long and the transforms cost more
+    // than the multiplies saved.  FD_WINO_MIN_MID overrides the channel count (measurements).
+    static const int wino_min_mid = getenv("FD_WINO_MIN_MID") ? atoi(getenv("FD_WINO_MIN_MID")) : (d->winograd == 4 ? 128 : 256);
+    if (stride == 1 && mid >= wino_min_mid) {
         std::vector<float> uw;
         int cout_pad = 0;
-        FD_TRY(wino_pack_weights(w2->data_host, mid, mid, s3.data(), &uw, &cout_pad));
+        FD_TRY(wino_pack_weights(w2->data_host, mid, mid, s3.data(), d->winograd ? d->winograd : 2, &uw, &cout_pad));
         float* ud = nullptr;
         FD_TRY(upload(d, uw.data(), uw.size(), &ud));
-        u->w_conv2.cin = mid; u->w_conv2.cout = mid; u->w_conv2.cout_pad = cout_pad;
+        u->w_conv2.cin = mid; u->w_conv2.cout = mid; u->w_conv2.cout_pad = cout_pad; u->w_conv2.tile = d->winograd ? d->winograd : 2;
         u->w_conv2.u = ud; u->w_conv2.bias = u->f_conv2.bias; u->w_conv2.relu = 1;
     }
     u->has_sc = !dim_match;
@@ -273,10 +278,11 @@ static int build(fd_detector* d, const ParamTable& t) {
         {
             std::vector<float> u;
             int cout_pad = 0;
-            FD_TRY(wino_pack_weights(w->data_host, 512, 1024, nullptr, &u, &cout_pad));
+            FD_TRY(wino_pack_weights(w->data_host, 512, 1024, nullptr, d->winograd ? d->winograd : 2, &u, &cout_pad));
             float* ud = nullptr;
             FD_TRY(upload(d, u.data(), u.size(), &ud));
             d->w_rpn_conv.cin = 1024; d->w_rpn_conv.cout = 512; d->w_rpn_conv.cout_pad = cout_pad;
+            d->w_rpn_conv.tile = d->winograd ? d->winograd : 2;
             d->w_rpn_conv.u = ud; d->w_rpn_conv.bias = d->f_rpn_conv.bias; d->w_rpn_conv.relu = 1;
         }
         const int A = d->prop.num_ratios * d->prop.num_scales;
@@ -505,9 +511,9 @@ static int run_unit_split(Plan& pl, const Unit& u, const char* name, const void*
                        (h * w > 49 || (long long)n * h * w >= 16384);
     float *wino_v = nullptr, *wino_m = nullptr;
     if (wino2) {
-        const size_t tp = (size_t)wino_patches_padded(n, h, w);
-        wino_v = pl.buf(NB_WINO_V, 16 * tp * u.w_conv2.cin);
-        wino_m = pl.buf(NB_WINO_M, 16 * tp * u.w_conv2.cout);
+        const size_t tp = (size_t)wino_patches_padded(n, h, w, u.w_conv2.tile), nb = (size_t)(u.w_conv2.tile + 2) * (u.w_conv2.tile + 2);
+        wino_v = pl.buf(NB_WINO_V, nb * tp * u.w_conv2.cin);
+        wino_m = pl.buf(NB_WINO_M, nb * tp * u.w_conv2.cout);
     }
     // the projection unit of the 64-channel stage as one kernel: shortcut and main branch are
     // accumulated together, so neither the shortcut tensor nor t1/t2 exist
@@ -650,9 +656,9 @@ static int run_graph_split(Plan& pl, const uint8_t* frames, int B, int H, int W,
     const bool wino = f32 && !layerwise && d->winograd && wino_fits(d->w_rpn_conv, B, fh, fw);
     float *wino_v = nullptr, *wino_m = nullptr;
     if (wino) {
-        const size_t tp = (size_t)wino_patches_padded(B, fh, fw);
-        wino_v = pl.buf(NB_WINO_V, 16 * tp * d->w_rpn_conv.cin);
-        wino_m = pl.buf(NB_WINO_M, 16 * tp * d->w_rpn_conv.cout);
+        const size_t tp = (size_t)wino_patches_padded(B, fh, fw, d->w_rpn_conv.tile), nb = (size_t)(d->w_rpn_conv.tile + 2) * (d->w_rpn_conv.tile + 2);
+        wino_v = pl.buf(NB_WINO_V, nb * tp * d->w_rpn_conv.cin);
+        wino_m = pl.buf(NB_WINO_M, nb * tp * d->w_rpn_conv.cout);
     }
     if (!pl.dry) {
         SplitConvOut o1 = pl.out(), o2 = pl.out();
@@ -849,7 +855,10 @@ int fd_detector_create(fd_ctx* ctx, const fd_param* params, int n_params, const 
     fd_detector* d = new fd_detector();
     d->ctx = ctx;
     if (const char* e = getenv("FD_FUSE_UNITS")) d->fuse_units = atoi(e);
-    if (const char* e = getenv("FD_WINOGRAD")) d->winograd = atoi(e) != 0;
+    if (const char* e = getenv("FD_WINOGRAD")) {
+        const int v = atoi(e);
+        d->winograd = v == 0 ? 0 : (v == 4 ? 4 : 2);          // 1 and 2: F(2x2,3x3)
+    }
     d->prop = *cfg;
     const int rc = fd::build(d, t);
     if (rc != FD_OK) {

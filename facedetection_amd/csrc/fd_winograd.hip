@@ -13,7 +13,14 @@
 // The transform matrices hold only 0, +-1 (and +-1/2 in G, applied to the weights in double on the
 // host), so the transforms are additions; measured against float64 the result carries about twice
 // the rounding noise of a direct float32 convolution (rms 4.8e-7 against 2.1e-7 of the output rms at
-// K = 9216).  F(4x4, 3x3) would need a quarter of the multiplies but ten times the noise: not used.
+// K = 9216).
+// F(4x4, 3x3) (tile = 4) computes a 4x4 block of outputs from a 6x6 patch with 36 multiplies per channel pair
+// instead of 144: 36 GEMMs over a quarter as many patches, and Winograd-domain tensors 2.25x the size of the
+// plain ones instead of 4x.  With the textbook interpolation points 0, +-1, +-2 its transforms amplify
+// rounding errors about six times more than F(2x2)'s; the points used here, 0, +-5/8, +-3/2 (all transform
+// entries stay exact binary fractions), bring that to about three times (simulated with float32 transforms and
+// sequential float32 accumulation over 1024 channels: rms error 2.5e-6 of the output rms against 5.7e-6 for the
+// textbook points, 0.9e-6 for F(2x2) and 1.5e-6 for the direct sum over 9216 products).
 #include "fd_conv_split.h"
 #include "fd_split.h"
 
@@ -112,26 +119,150 @@ __global__ __launch_bounds__(256) void wino_output_kernel(const float* __restric
     }
 }
 
-// U[xi = i * 4 + j][o][c] = (G g G^T)[i][j] of filter (o, c), G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]],
-// computed in double from the OIHW weights (times out_scale[o] when given), rounded once to float32.
-int wino_pack_weights(const float* w_oihw, int cout, int cin, const float* out_scale, std::vector<float>* packed,
-                      int* cout_pad_out) {
-    FD_REQUIRE(w_oihw && packed && cout > 0 && cin > 0, "wino_pack_weights: bad arguments");
+// ---------------------------------------------------------------------------------
+// F(4x4, 3x3) with the interpolation points 0, 5/8, -5/8, 3/2, -3/2 and infinity (Cook-Toom construction:
+// row j of B^T holds the coefficients of the product of (x - p_l) over the finite points l != j, the last row
+// that of the product over all of them; A^T is the Vandermonde matrix of the points; G the same scaled by
+// 1 / prod_{l != j} (p_j - p_l), computed on the host).
+constexpr float W4_BT[6][6] = {
+    {0.87890625f, 0.0f, -2.640625f, 0.0f, 1.0f, 0.0f},
+    {0.0f, -1.40625f, -2.25f, 0.625f, 1.0f, 0.0f},
+    {0.0f, 1.40625f, -2.25f, -0.625f, 1.0f, 0.0f},
+    {0.0f, -0.5859375f, -0.390625f, 1.5f, 1.0f, 0.0f},
+    {0.0f, 0.5859375f, -0.390625f, -1.5f, 1.0f, 0.0f},
+    {0.0f, 0.87890625f, 0.0f, -2.640625f, 0.0f, 1.0f},
+};
+constexpr float W4_AT[4][6] = {
+    {1.0f, 1.0f, 1.0f, 1.0f, 1.0f, 0.0f},
+    {0.0f, 0.625f, -0.625f, 1.5f, -1.5f, 0.0f},
+    {0.0f, 0.390625f, 0.390625f, 2.25f, 2.25f, 0.0f},
+    {0.0f, 0.244140625f, -0.244140625f, 3.375f, -3.375f, 1.0f},
+};
+
+// sum_k coef[k] * v[k] over the non-zero coefficients (the table is a compile-time constant: after unrolling
+// only the multiplies that exist remain)
+template <int N>
+__device__ __forceinline__ f32x4 wino_dot(const float (&coef)[N], const f32x4 (&v)[N]) {
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    bool first = true;
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        if (coef[k] == 0.f) continue;
+        if (first) acc = coef[k] == 1.f ? v[k] : v[k] * coef[k];
+        else acc += v[k] * coef[k];
+        first = false;
+    }
+    return acc;
+}
+
+// one thread: one 6x6 patch (4x4 outputs), 4 consecutive channels
+__global__ __launch_bounds__(256) void wino4_input_kernel(const float* __restrict__ x, int B, int H, int W, int C, int th,
+                                                         int tw, long long T_pad, float* __restrict__ V) {
+    const int c4n = C >> 2;
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long t = idx / c4n;
+    const int c = (int)(idx - t * c4n) * 4;
+    if (t >= (long long)B * th * tw) return;
+    const int tx = (int)(t % tw);
+    const int ty = (int)((t / tw) % th);
+    const int b = (int)(t / ((long long)tw * th));
+    const int y0 = 4 * ty - 1, x0 = 4 * tx - 1;
+    f32x4 r[6][6];                                   // B^T d, column by column
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        f32x4 d[6];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            const int yy = y0 + i, xx = x0 + j;
+            d[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if ((unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W)
+                d[i] = *reinterpret_cast<const f32x4*>(x + (((size_t)b * H + yy) * W + xx) * C + c);
+        }
+#pragma unroll
+        for (int i = 0; i < 6; ++i) r[i][j] = wino_dot(W4_BT[i], d);
+    }
+    const size_t plane = (size_t)T_pad * C;
+    float* o = V + (size_t)t * C + c;
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+        for (int j = 0; j < 6; ++j) *reinterpret_cast<f32x4*>(o + (i * 6 + j) * plane) = wino_dot(W4_BT[j], r[i]);
+}
+
+// one thread: one patch (4x4 outputs), 4 consecutive output channels
+__global__ __launch_bounds__(256) void wino4_output_kernel(const float* __restrict__ M, int B, int H, int W, int Cout,
+                                                          int th, int tw, long long T_pad, const float* __restrict__ bias,
+                                                          int relu, float* __restrict__ y) {
+    const int c4n = Cout >> 2;
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long t = idx / c4n;
+    const int c = (int)(idx - t * c4n) * 4;
+    if (t >= (long long)B * th * tw) return;
+    const int tx = (int)(t % tw);
+    const int ty = (int)((t / tw) % th);
+    const int b = (int)(t / ((long long)tw * th));
+    const size_t plane = (size_t)T_pad * Cout;
+    const float* p = M + (size_t)t * Cout + c;
+    f32x4 s[4][6];                                   // A^T m, column by column
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        f32x4 m[6];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) m[i] = *reinterpret_cast<const f32x4*>(p + (i * 6 + j) * plane);
+#pragma unroll
+        for (int a = 0; a < 4; ++a) s[a][j] = wino_dot(W4_AT[a], m);
+    }
+    const f32x4 bv = bias ? *reinterpret_cast<const f32x4*>(bias + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        const int yy = 4 * ty + a;
+        if (yy >= H) continue;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int xx = 4 * tx + q;
+            if (xx >= W) continue;
+            f32x4 o = wino_dot(W4_AT[q], s[a]) + bv;
+            if (relu) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = fmaxf(o[e], 0.f);
+            }
+            *reinterpret_cast<f32x4*>(y + (((size_t)b * H + yy) * W + xx) * Cout + c) = o;
+        }
+    }
+}
+
+// U[xi = i * n + j][o][c] = (G g G^T)[i][j] of filter (o, c), n = tile + 2, computed in double from the OIHW
+// weights (times out_scale[o] when given) and rounded once to float32.
+// tile 2: G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]];  tile 4: row j = (1, p_j, p_j^2) / prod_{l != j} (p_j - p_l).
+int wino_pack_weights(const float* w_oihw, int cout, int cin, const float* out_scale, int tile,
+                      std::vector<float>* packed, int* cout_pad_out) {
+    FD_REQUIRE(w_oihw && packed && cout > 0 && cin > 0 && (tile == 2 || tile == 4), "wino_pack_weights: bad arguments");
     const int cout_pad = (cout + 127) / 128 * 128;
-    packed->assign((size_t)16 * cout_pad * cin, 0.f);
-    static const double G[4][3] = {{1, 0, 0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0, 0, 1}};
+    const int n = tile + 2;
+    packed->assign((size_t)n * n * cout_pad * cin, 0.f);
+    double G[6][3] = {{1, 0, 0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0, 0, 1}, {0, 0, 0}, {0, 0, 0}};
+    if (tile == 4) {
+        const double pts[5] = {0.0, 0.625, -0.625, 1.5, -1.5};
+        for (int j = 0; j < 5; ++j) {
+            double nj = 1.0;
+            for (int l = 0; l < 5; ++l)
+                if (l != j) nj *= pts[j] - pts[l];
+            G[j][0] = 1.0 / nj; G[j][1] = pts[j] / nj; G[j][2] = pts[j] * pts[j] / nj;
+        }
+        G[5][0] = 0.0; G[5][1] = 0.0; G[5][2] = 1.0;
+    }
     for (int o = 0; o < cout; ++o) {
         const double sc = out_scale ? (double)out_scale[o] : 1.0;
         for (int c = 0; c < cin; ++c) {
             const float* g = w_oihw + ((size_t)o * cin + c) * 9;
-            double gg[4][3];
-            for (int i = 0; i < 4; ++i)
+            double gg[6][3];
+            for (int i = 0; i < n; ++i)
                 for (int k = 0; k < 3; ++k)
                     gg[i][k] = G[i][0] * g[0 * 3 + k] + G[i][1] * g[1 * 3 + k] + G[i][2] * g[2 * 3 + k];
-            for (int i = 0; i < 4; ++i)
-                for (int j = 0; j < 4; ++j) {
+            for (int i = 0; i < n; ++i)
+                for (int j = 0; j < n; ++j) {
                     const double u = gg[i][0] * G[j][0] + gg[i][1] * G[j][1] + gg[i][2] * G[j][2];
-                    (*packed)[((size_t)(i * 4 + j) * cout_pad + o) * cin + c] = (float)(u * sc);
+                    (*packed)[((size_t)(i * n + j) * cout_pad + o) * cin + c] = (float)(u * sc);
                 }
         }
     }
@@ -139,36 +270,46 @@ int wino_pack_weights(const float* w_oihw, int cout, int cin, const float* out_s
     return FD_OK;
 }
 
-long long wino_patches_padded(int batch, int h, int w) {
-    const long long T = (long long)batch * ((h + 1) / 2) * ((w + 1) / 2);
+long long wino_patches_padded(int batch, int h, int w, int tile) {
+    const long long T = (long long)batch * ((h + tile - 1) / tile) * ((w + tile - 1) / tile);
     return (T + 127) / 128 * 128;
 }
 
 bool wino_fits(const WinoConvParams& p, int batch, int h, int w) {
-    const long long T_pad = wino_patches_padded(batch, h, w);
-    return p.u && p.cin % 32 == 0 && p.cout % 8 == 0 && 16 * T_pad * p.cin * 4 < (1ll << 31) &&
-           16 * T_pad * (long long)p.cout * 4 < (1ll << 33) && 16 * T_pad < (1ll << 29) &&
-           16ll * p.cout_pad * p.cin * 4 < (1ll << 31);
+    const long long T_pad = wino_patches_padded(batch, h, w, p.tile);
+    const long long nb = (p.tile + 2) * (p.tile + 2);
+    return p.u && (p.tile == 2 || p.tile == 4) && p.cin % 32 == 0 && p.cout % 8 == 0 && nb * T_pad * p.cin * 4 < (1ll << 31) &&
+           nb * T_pad * (long long)p.cout * 4 < (1ll << 33) && nb * T_pad < (1ll << 29) &&
+           nb * p.cout_pad * p.cin * 4 < (1ll << 31);
 }
 
 int wino_conv_forward(const WinoConvParams& p, const float* x, int batch, int h, int w, float* v_ws, float* m_ws,
                       float* y, hipStream_t stream) {
     FD_REQUIRE(x && y && v_ws && m_ws && wino_fits(p, batch, h, w), "winograd convolution: bad arguments or sizes");
-    const int th = (h + 1) / 2, tw = (w + 1) / 2;
-    const long long T = (long long)batch * th * tw, T_pad = wino_patches_padded(batch, h, w);
+    const int tile = p.tile, nb = (tile + 2) * (tile + 2);
+    const int th = (h + tile - 1) / tile, tw = (w + tile - 1) / tile;
+    const long long T = (long long)batch * th * tw, T_pad = wino_patches_padded(batch, h, w, tile);
     {
-        ProfScope scope(stream, "wino_input", 0.0, 4.0 * p.cin * ((double)batch * h * w + 16.0 * T));
+        ProfScope scope(stream, "wino_input", 0.0, 4.0 * p.cin * ((double)batch * h * w + (double)nb * T));
         const long long items = T * (p.cin / 4);
-        hipLaunchKernelGGL(wino_input_kernel, dim3((unsigned)ceil_div(items, 256)), dim3(256), 0, stream, x, batch, h, w,
-                           p.cin, th, tw, T_pad, v_ws);
+        if (tile == 4)
+            hipLaunchKernelGGL(wino4_input_kernel, dim3((unsigned)ceil_div(items, 256)), dim3(256), 0, stream, x, batch, h,
+                               w, p.cin, th, tw, T_pad, v_ws);
+        else
+            hipLaunchKernelGGL(wino_input_kernel, dim3((unsigned)ceil_div(items, 256)), dim3(256), 0, stream, x, batch, h,
+                               w, p.cin, th, tw, T_pad, v_ws);
         FD_LAUNCH_CHECK();
     }
-    FD_TRY(gemm_f32_batched(v_ws, p.u, 16, (int)T_pad, p.cin, p.cout, p.cout_pad, m_ws, stream));
+    FD_TRY(gemm_f32_batched(v_ws, p.u, nb, (int)T_pad, p.cin, p.cout, p.cout_pad, m_ws, stream));
     {
-        ProfScope scope(stream, "wino_output", 0.0, 4.0 * p.cout * (16.0 * T + (double)batch * h * w));
+        ProfScope scope(stream, "wino_output", 0.0, 4.0 * p.cout * ((double)nb * T + (double)batch * h * w));
         const long long items = T * (p.cout / 4);
-        hipLaunchKernelGGL(wino_output_kernel, dim3((unsigned)ceil_div(items, 256)), dim3(256), 0, stream, m_ws, batch, h,
-                           w, p.cout, th, tw, T_pad, p.bias, p.relu, y);
+        if (tile == 4)
+            hipLaunchKernelGGL(wino4_output_kernel, dim3((unsigned)ceil_div(items, 256)), dim3(256), 0, stream, m_ws, batch,
+                               h, w, p.cout, th, tw, T_pad, p.bias, p.relu, y);
+        else
+            hipLaunchKernelGGL(wino_output_kernel, dim3((unsigned)ceil_div(items, 256)), dim3(256), 0, stream, m_ws, batch,
+                               h, w, p.cout, th, tw, T_pad, p.bias, p.relu, y);
         FD_LAUNCH_CHECK();
     }
     return FD_OK;
@@ -179,8 +320,9 @@ int wino_conv_forward(const WinoConvParams& p, const float* x, int batch, int h,
 extern "C" {
 
 int fd_conv2d_winograd(fd_ctx* ctx, const float* x_nhwc, int batch, int height, int width, int cin, const float* w_oihw,
-                       int cout, const float* bias, int relu, float* y_nhwc, void* stream) {
+                       int cout, const float* bias, int relu, int tile, float* y_nhwc, void* stream) {
     FD_REQUIRE(ctx && x_nhwc && w_oihw && y_nhwc, "fd_conv2d_winograd: NULL argument");
+    FD_REQUIRE(tile == 2 || tile == 4, "fd_conv2d_winograd: tile must be 2 (F(2x2,3x3)) or 4 (F(4x4,3x3)), got %d", tile);
     FD_REQUIRE(batch > 0 && height > 0 && width > 0 && cin > 0 && cin % 32 == 0 && cout > 0 && cout % 8 == 0,
                "fd_conv2d_winograd: cin must be a multiple of 32 and cout of 8 (got %d, %d)", cin, cout);
     hipStream_t st = fd::as_stream(stream);
@@ -191,8 +333,8 @@ int fd_conv2d_winograd(fd_ctx* ctx, const float* x_nhwc, int batch, int height, 
     FD_HIP(hipStreamSynchronize(st));
     FD_HIP(hipMemcpy(host.data(), w_oihw, nw * sizeof(float), hipMemcpyDeviceToHost));
     fd::WinoConvParams p;
-    p.cin = cin; p.cout = cout; p.bias = bias; p.relu = relu;
-    FD_TRY(fd::wino_pack_weights(host.data(), cout, cin, nullptr, &packed, &p.cout_pad));
+    p.cin = cin; p.cout = cout; p.bias = bias; p.relu = relu; p.tile = tile;
+    FD_TRY(fd::wino_pack_weights(host.data(), cout, cin, nullptr, tile, &packed, &p.cout_pad));
     void *u = nullptr, *v = nullptr, *m = nullptr;
     FD_TRY(fd::scratch(ctx, fd::SLOT_MISC0, packed.size() * sizeof(float), &u));
     FD_HIP(hipMemcpyAsync(u, packed.data(), packed.size() * sizeof(float), hipMemcpyHostToDevice, st));
@@ -201,9 +343,9 @@ int fd_conv2d_winograd(fd_ctx* ctx, const float* x_nhwc, int batch, int height, 
     FD_REQUIRE(fd::wino_fits(p, batch, height, width),
                "fd_conv2d_winograd: problem beyond the 32-bit reach of the kernels (batch %d, %d x %d, %d -> %d)", batch,
                height, width, cin, cout);
-    const size_t tp = (size_t)fd::wino_patches_padded(batch, height, width);
-    FD_TRY(fd::scratch(ctx, fd::SLOT_MISC1, 16 * tp * cin * sizeof(float), &v));
-    FD_TRY(fd::scratch(ctx, fd::SLOT_MISC2, 16 * tp * cout * sizeof(float), &m));
+    const size_t tp = (size_t)fd::wino_patches_padded(batch, height, width, tile), nb = (size_t)(tile + 2) * (tile + 2);
+    FD_TRY(fd::scratch(ctx, fd::SLOT_MISC1, nb * tp * cin * sizeof(float), &v));
+    FD_TRY(fd::scratch(ctx, fd::SLOT_MISC2, nb * tp * cout * sizeof(float), &m));
     return fd::wino_conv_forward(p, x_nhwc, batch, height, width, static_cast<float*>(v), static_cast<float*>(m),
                                  y_nhwc, st);
 }

@@ -124,13 +124,13 @@ def conv2d(x, weight, stride=1, pad=0, bias=None, pre_scale=None, pre_shift=None
     dev = lambda a: None if a is None else runtime.to_device(a, torch.float32)
     xd, wd, bd, sd, hd, rd = dev(x), dev(weight), dev(bias), dev(pre_scale), dev(pre_shift), dev(residual)
     y = runtime.empty((B, Ho, Wo, Cout), torch.float32)
-    if precision == "winograd":
-        # float32, Winograd F(2x2,3x3): the 3x3 / stride 1 / pad 1 case without prologue or residual
+    if precision in ("winograd", "winograd4"):
+        # float32, Winograd F(2x2,3x3) or F(4x4,3x3): the 3x3 / stride 1 / pad 1 case without prologue or residual
         if (kh, kw, int(stride), int(pad)) != (3, 3, 1, 1) or sd is not None or hd is not None or rd is not None:
             raise ValueError("conv2d: the Winograd form is the plain 3x3, stride 1, pad 1 convolution")
         _lib.check(_lib.lib().fd_conv2d_winograd(ctx.handle, runtime.ptr(xd), B, H, W, Cin, runtime.ptr(wd), Cout,
-                                                  runtime.ptr(bd), 1 if relu else 0, runtime.ptr(y),
-                                                  runtime.stream_ptr()))
+                                                  runtime.ptr(bd), 1 if relu else 0, 4 if precision == "winograd4" else 2,
+                                                  runtime.ptr(y), runtime.stream_ptr()))
         return y.cpu().numpy() if as_np else y
     fn = _lib.lib().fd_conv2d if precision == "f32" else _lib.lib().fd_conv2d_f16x3
     _lib.check(fn(ctx.handle, runtime.ptr(xd), B, H, W, Cin, runtime.ptr(wd), Cout, kh, kw,

@@ -198,13 +198,13 @@ int fd_conv2d_f16x3(fd_ctx* ctx, const float* x_nhwc, int batch, int height, int
                     const float* pre_scale, const float* pre_shift, int relu, const float* residual,
                     float* y_nhwc, void* stream);
 
-/* The 3x3, stride 1, pad 1 case of the same operator in Winograd F(2x2,3x3) form, float32 (the form the
- * detector uses for the RPN's 3x3 convolution, faster_rcnn.py:85-87, and the wide 3x3 layers of
- * faster_rcnn.py:41-43 in FD_PRECISION_F32): y = [relu](conv3x3(x) + bias).  4/9 of the multiplies of the
- * direct form; about twice its rounding noise.  cin a multiple of 32, cout of 8.  Transforms the weights on
- * the host: synchronous. */
+/* The 3x3, stride 1, pad 1 case of the same operator in Winograd form, float32 (the form the detector uses
+ * for the RPN's 3x3 convolution, faster_rcnn.py:85-87, and the wide 3x3 layers of faster_rcnn.py:41-43 in
+ * FD_PRECISION_F32): y = [relu](conv3x3(x) + bias).  tile = 2: F(2x2,3x3), 4/9 of the multiplies of the
+ * direct form; tile = 4: F(4x4,3x3), 1/4 of them (interpolation points 0, +-5/8, +-3/2).  cin a multiple of
+ * 32, cout of 8.  Transforms the weights on the host: synchronous. */
 int fd_conv2d_winograd(fd_ctx* ctx, const float* x_nhwc, int batch, int height, int width, int cin, const float* w_oihw,
-                       int cout, const float* bias, int relu, float* y_nhwc, void* stream);
+                       int cout, const float* bias, int relu, int tile, float* y_nhwc, void* stream);
 
 /* Detector ------------------------------------------------------------------------------
  * Detector.__init__ (detection.py:26-31): takes the checkpoint's tensors by their MXNet names

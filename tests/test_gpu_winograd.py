@@ -1,7 +1,8 @@
-"""precision="f32" runs the 3x3 convolutions of the 256-channel stage and of the RPN by Winograd
-F(2x2, 3x3): 4/9 of the multiplies of the direct form, transforms made of additions only.  Checked
-against the direct float32 convolutions of a layer-by-layer pass (same weights) on feature maps with
-odd and even sides, and against float64 arithmetic on the RPN layer alone."""
+"""precision="f32" runs the 3x3 convolutions of the 256-channel stage and of the RPN by Winograd's minimal
+filtering: F(4x4, 3x3) by default (a quarter of the multiplies of the direct form), F(2x2, 3x3) with
+FD_WINOGRAD=2 (4/9 of them, transforms made of additions only).  Checked against the direct float32
+convolutions of a layer-by-layer pass (same weights) on feature maps with odd and even sides, and against
+float64 arithmetic on the RPN layer alone and on the operator."""
 import numpy as np
 import pytest
 import torch
@@ -11,8 +12,10 @@ pytestmark = pytest.mark.gpu
 SIZES = [(1, 37, 41), (3, 64, 96), (2, 333, 517), (1, 270, 480), (2, 1080, 1920)]
 
 
-def test_winograd_rpn_convolution_matches_the_direct_float32_kernel():
+@pytest.mark.parametrize("tile", ["4", "2"])
+def test_winograd_rpn_convolution_matches_the_direct_float32_kernel(monkeypatch, tile):
     from facedetection_amd.detection import Detector
+    monkeypatch.setenv("FD_WINOGRAD", tile)
     lay = Detector("synthetic:0", 0, own_context=True, precision="f32")
     new = Detector("synthetic:0", 0, own_context=True, precision="f32")
     lay.keep_tensors(True)                       # layer by layer: direct convolution
@@ -54,7 +57,7 @@ def test_winograd_rpn_convolution_against_float64(monkeypatch):
     errs = {}
     rng = np.random.default_rng(6)
     frames = rng.integers(0, 256, size=(1, 333, 517, 3), dtype=np.uint8)
-    for mode in ("1", "0"):
+    for mode in ("4", "2", "0"):
         monkeypatch.setenv("FD_WINOGRAD", mode)
         det = Detector("synthetic:0", 0, own_context=True, precision="f32")
         det.keep_tensors(True, production=True)
@@ -68,16 +71,18 @@ def test_winograd_rpn_convolution_against_float64(monkeypatch):
         finally:
             det.close()
     assert errs["0"] <= 5e-6, errs
-    assert errs["1"] <= 4 * max(errs["0"], 5e-7), errs
+    assert errs["2"] <= 4 * max(errs["0"], 5e-7), errs
+    assert errs["4"] <= 6 * max(errs["0"], 5e-7), errs
 
 
 @pytest.mark.parametrize("b,h,w,cin,cout", [(1, 1, 1, 32, 8), (2, 5, 7, 32, 72), (3, 8, 8, 64, 64), (1, 37, 51, 96, 40),
                                             (2, 68, 120, 256, 256)])
 @pytest.mark.parametrize("relu", [False, True])
-def test_winograd_operator_against_float64(b, h, w, cin, cout, relu):
+@pytest.mark.parametrize("form", ["winograd", "winograd4"])
+def test_winograd_operator_against_float64(b, h, w, cin, cout, relu, form):
     """The operator alone (fd_conv2d_winograd through the C ABI) on odd and even map sizes, a single pixel,
     channel counts that leave GEMM tiles ragged; float64 torch convolution as the reference, and the
-    direct float32 kernel next to it: the Winograd form may carry a few times its rounding noise."""
+    direct float32 kernel next to it: the Winograd forms may carry a few times its rounding noise."""
     from facedetection_amd import ops
     rng = np.random.default_rng(b * 1000 + h)
     x = rng.standard_normal((b, h, w, cin)).astype(np.float32)
@@ -88,10 +93,11 @@ def test_winograd_operator_against_float64(b, h, w, cin, cout, relu):
     if relu:
         ref = torch.relu(ref)
     ref = ref.permute(0, 2, 3, 1).numpy()
-    got = ops.conv2d(x, wt, stride=1, pad=1, bias=bias, relu=relu, precision="winograd")
+    got = ops.conv2d(x, wt, stride=1, pad=1, bias=bias, relu=relu, precision=form)
     direct = ops.conv2d(x, wt, stride=1, pad=1, bias=bias, relu=relu, precision="f32")
     assert got.shape == ref.shape
     scale = max(float(np.abs(ref).max()), 1.0)
     e_w, e_d = float(np.abs(got - ref).max()) / scale, float(np.abs(direct - ref).max()) / scale
     assert e_d <= 3e-6, e_d
-    assert e_w <= max(4 * e_d, 2e-6), (e_w, e_d)
+    # F(2x2): transforms of additions only; F(4x4): fractional entries up to 3.4, about three times the noise
+    assert e_w <= (max(4 * e_d, 2e-6) if form == "winograd" else max(8 * e_d, 5e-6)), (e_w, e_d)
