@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Per-layer convolution timing from a rocprofv3 kernel trace of bench.py.
 
-    python tools/conv_layer_report.py <kernel_trace.csv> [micro_batch] [f16x3 | f32 | layers]
+    python tools/conv_layer_report.py <kernel_trace.csv> [micro_batch] [f16x3 | f32 | layers] [winograd tile: 4 | 2]
 
 Takes the convolution launches of the last complete forward pass in the trace, pairs them with
 the launch list of faster_rcnn50 at 1080p (same order as the library issues them, see layer_list)
@@ -11,20 +11,22 @@ import csv
 import sys
 
 
-def layer_list(B, H=1080, W=1920, R=10, mode="f16x3"):
+def layer_list(B, H=1080, W=1920, R=10, mode="f16x3", tile=4):
     """Convolution launches of one forward pass in issue order: (name, M, N, K, FLOPs executed).
     mode "f16x3": the stem runs fused with the max-pool and each unit of the 64-channel stage is one kernel;
     mode "f32": fused stem, the 3x3 + 1x1 tail of each 64-channel unit is one kernel, and the stride-1 3x3
-    layers from 256 channels on (and the RPN's) are one batched Winograd GEMM launch each (4/9 of the
-    direct FLOPs, rows padded to whole tiles); mode "layers": every layer its own launch."""
+    layers from 128 channels on (256 with tile 2) and the RPN's are one batched Winograd GEMM launch each
+    ((tile + 2)^2 GEMMs over the tile x tile patches: 1/4 of the direct FLOPs with tile 4, 4/9 with tile 2,
+    rows padded to whole GEMM tiles); mode "layers": every layer its own launch."""
     layers = []
 
     def conv(name, n, h, w, cin, cout, k, s, p, wino=False):
         ho, wo = (h + 2 * p - k) // s + 1, (w + 2 * p - k) // s + 1
         if wino:
-            t = n * ((h + 1) // 2) * ((w + 1) // 2)
+            t = n * ((h + tile - 1) // tile) * ((w + tile - 1) // tile)
             tp = (t + 127) // 128 * 128
-            layers.append((name + "w", 16 * tp, cout, cin, 2.0 * 16 * tp * cout * cin))
+            nb = (tile + 2) ** 2
+            layers.append((name + "w", nb * tp, cout, cin, 2.0 * nb * tp * cout * cin))
         else:
             layers.append((name, n * ho * wo, cout, cin * k * k, 2.0 * n * ho * wo * cout * cin * k * k))
         return ho, wo
@@ -47,7 +49,7 @@ def layer_list(B, H=1080, W=1920, R=10, mode="f16x3"):
             if u == 0:
                 conv(nm + "_sc", n, h, w, cin, cout, 1, st, 0)
             conv(nm + "_c1", n, h, w, cin, mid, 1, 1, 0)
-            wino = mode == "f32" and st == 1 and mid >= 256 and (h * w > 49 or n * h * w >= 16384)
+            wino = mode == "f32" and st == 1 and mid >= (128 if tile == 4 else 256) and (h * w > 49 or n * h * w >= 16384)
             h2, w2 = conv(nm + "_c2", n, h, w, mid, mid, 3, st, 1, wino=wino)
             conv(nm + "_c3", n, h2, w2, mid, cout, 1, 1, 0)
             if mid == 64 and st == 1 and mode != "layers":
@@ -65,7 +67,7 @@ def main():
     B = int(sys.argv[2]) if len(sys.argv) > 2 else 8
     rows = [r for r in csv.DictReader(open(path))
             if any(t in r["Kernel_Name"] for t in ("conv_igemm", "conv_split_", "stem_pool", "conv_tail_fused", "unit_fused", "unit_proj_fused"))]
-    layers = layer_list(B, mode=sys.argv[3] if len(sys.argv) > 3 else "f16x3")
+    layers = layer_list(B, mode=sys.argv[3] if len(sys.argv) > 3 else "f16x3", tile=int(sys.argv[4]) if len(sys.argv) > 4 else 4)
     last = rows[-len(layers):]
     tot = totf = 0.0
     groups = {}
