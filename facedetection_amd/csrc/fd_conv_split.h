@@ -90,18 +90,37 @@ struct WinoConvParams {
     const float* u = nullptr;      // transformed weights [(tile + 2)^2][cout_pad][cin] (device)
     const float* bias = nullptr;   // [cout] or NULL
     int relu = 0;
+    // split-precision form of the same transformed weights (fp16 hi+lo pairs, packed per GEMM like 1x1
+    // convolution weights, times a power of two 1 / u_inv_scale); NULL: float32 only
+    const void* u_split = nullptr;
+    float u_inv_scale = 1.f;
+    unsigned u_split_bytes = 0;    // bytes per GEMM's weight set
 };
 // host: OIHW weights -> the transformed layout above (float32 values computed in double)
 int wino_pack_weights(const float* w_oihw, int cout, int cin, const float* out_scale, int tile, std::vector<float>* packed,
                       int* cout_pad);
 // number of tile x tile output patches of a batch, rounded up to whole 128-row GEMM tiles
-long long wino_patches_padded(int batch, int h, int w, int tile);
+long long wino_patches_padded(int batch, int h, int w, int tile, int align = 128);
 // whether the 32-bit offsets of the kernels reach every tensor of this problem
 bool wino_fits(const WinoConvParams& p, int batch, int h, int w);
 // x [B][H][W][cin] float32 -> y [B][H][W][cout] float32 (+ bias, ReLU).  Workspaces: v_ws holds
 // (tile + 2)^2 * wino_patches_padded * cin floats, m_ws (tile + 2)^2 * wino_patches_padded * cout floats.
 int wino_conv_forward(const WinoConvParams& p, const float* x, int batch, int h, int w, float* v_ws, float* m_ws,
                       float* y, hipStream_t stream);
+// Split-precision form (tile 4 only): x and y are split tensors (fd_split.h), the Winograd-domain input V is a
+// split tensor too (same bytes as float32), the GEMMs run on the f16 matrix cores (three MFMAs per product) and
+// leave M in float32.  Patches are padded to whole 256-row GEMM tiles: wino_patches_padded(..., 256).
+// device: packs the float32 transformed weights `u` (device, [36][cout_pad][cin]) into `packed` (36 sets of
+// split_weight_floats(cin, cout) floats) scaled by `wscale`
+size_t wino_split_weight_floats(int cin, int cout);
+int wino_pack_weights_split(const float* u_dev, int cin, int cout, int cout_pad, float wscale, void* packed, hipStream_t stream);
+bool wino_fits_split(const WinoConvParams& p, int batch, int h, int w);
+int wino_conv_forward_split(const WinoConvParams& p, const void* x_split, int batch, int h, int w, void* v_ws, float* m_ws,
+                            void* y_split, unsigned* clamped, hipStream_t stream);
+// nb independent split-precision GEMMs in one launch (256 x 256 tiles): y[b] [rows_pad][cout] float32 =
+// a[b] [rows_pad][k] (split) * w[b]^T * w_inv_scale; rows_pad % 256 == 0, k % 32 == 0
+int gemm_split_batched(const void* a_split, const void* w_split, unsigned w_set_bytes, float w_inv_scale, int nb, int rows_pad,
+                       int k, int cout, float* y, hipStream_t stream);
 // nb independent float32 GEMMs in one launch on the 128 x 128 direct-to-LDS kernel:
 // y[b] [rows_pad][cout] = a[b] [rows_pad][k] * w[b]^T, w[b] = [cout_pad][k]; rows_pad % 128 == 0, k % 32 == 0.
 int gemm_f32_batched(const float* a, const float* w, int nb, int rows_pad, int k, int cout, int cout_pad, float* y,

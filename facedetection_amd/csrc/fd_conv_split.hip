@@ -962,6 +962,28 @@ int gemm_f32_batched(const float* a_mat, const float* w, int nb, int rows_pad, i
     return launch_split_glds<128, 128, 2, 4, true>(a, x_bytes, w_bytes, stream);
 }
 
+int gemm_split_batched(const void* a_split, const void* w_split, unsigned w_set_bytes, float w_inv_scale, int nb, int rows_pad,
+                       int k, int cout, float* y, hipStream_t stream) {
+    FD_REQUIRE(a_split && w_split && y && nb > 0 && rows_pad > 0 && rows_pad % 256 == 0 && k % 32 == 0 && cout % 8 == 0,
+               "gemm_split_batched: bad arguments");
+    const size_t x_bytes = (size_t)nb * rows_pad * k * 4, w_bytes = (size_t)nb * w_set_bytes;
+    FD_REQUIRE(x_bytes < (1ull << 31) && w_bytes < (1ull << 31) && (long long)nb * rows_pad < (1ll << 29),
+               "gemm_split_batched: operands beyond the 2^31-byte reach of the buffer-addressed kernel");
+    SplitKArgs a;
+    a.x = static_cast<const uint8_t*>(a_split);
+    a.w = static_cast<const uint8_t*>(w_split);
+    a.bias = nullptr; a.res = nullptr; a.y32 = y; a.ysplit = nullptr;
+    a.post_scale = a.post_shift = nullptr; a.pre_scale = a.pre_shift = nullptr; a.w_inv_scale = w_inv_scale;
+    a.H = 1; a.W = 1; a.Cin = k; a.Ho = 1; a.Wo = 1; a.Cout = cout; a.KW = 1; a.stride = 1; a.pad = 0; a.K = k;
+    a.M = nb * rows_pad; a.relu = 0; a.tiles_n = 0; a.ksplit = 1; a.kchunk = k / SBK; a.partial = nullptr;
+    a.clamped = nullptr; a.f32 = 0;
+    a.wbatch_tiles = rows_pad / 256;
+    a.wbatch_bytes = w_set_bytes;
+    // (256 x 128 and 128 x 128 tiles measured the same on the K = 256 GEMMs of the 256-channel stage)
+    if (cout >= 256) return launch_split_glds<256, 256, 2, 8>(a, x_bytes, w_bytes, stream);
+    return launch_split_glds<256, 128, 3, 8>(a, x_bytes, w_bytes, stream);
+}
+
 int split_conv_forward(const SplitConvParams& p, const void* x_split, int batch, int h, int w, const float* residual,
                        const SplitConvOut& out, hipStream_t stream) {
     return split_conv_dispatch(p, x_split, nullptr, nullptr, batch, h, w, residual, out, stream);

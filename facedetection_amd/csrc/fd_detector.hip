@@ -55,6 +55,8 @@ struct fd_detector {
     fd::WinoConvParams w_rpn_conv;       // the RPN's 3x3 convolution in Winograd form (float32 precision)
     int winograd = 4;                    // float32 precision: Winograd tile of the long-K 3x3 layers, 4 = F(4x4,3x3),
                                          // 2 = F(2x2,3x3), 0 = direct (environment variable FD_WINOGRAD)
+    bool winograd_split = true;          // f16x3 precision: F(4x4,3x3) for the RPN and the 256-channel stage when
+                                         // `winograd` is 4 (environment variable FD_WINOGRAD_SPLIT=0: direct)
     int precision = FD_PRECISION_F16X3;
     const float *bn1_scale = nullptr, *bn1_shift = nullptr;
     const float *w_cls = nullptr, *b_cls = nullptr, *w_box = nullptr, *b_box = nullptr;
@@ -108,6 +110,27 @@ static int upload(fd_detector* d, const float* host, size_t n, float** out) {
     d->owned.push_back(p);
     FD_HIP(hipMemcpy(p, host, n * sizeof(float), hipMemcpyHostToDevice));
     *out = static_cast<float*>(p);
+    return FD_OK;
+}
+
+// Split-precision form of a Winograd layer's transformed weights (F(4x4,3x3) only): the float32 set `u_dev`
+// (already on the device) scaled by a power of two that brings the largest magnitude to [2^13, 2^14), as for
+// ordinary convolution weights, and packed per GEMM.
+static int make_wino_split(fd_detector* d, const std::vector<float>& u_host, const float* u_dev, WinoConvParams* p) {
+    if (p->tile != 4 || p->cout % 32 != 0) return FD_OK;
+    double umax = 0.0;
+    for (float v : u_host) umax = std::max(umax, std::fabs((double)v));
+    float wscale = 1.f;
+    if (umax > 0.0 && std::isfinite(umax)) wscale = (float)std::ldexp(1.0, 13 - (int)std::floor(std::log2(umax)));
+    const size_t set_floats = wino_split_weight_floats(p->cin, p->cout);
+    void* packed = nullptr;
+    FD_HIP(hipMalloc(&packed, 36 * set_floats * sizeof(float)));
+    d->owned.push_back(packed);
+    FD_TRY(wino_pack_weights_split(u_dev, p->cin, p->cout, p->cout_pad, wscale, packed, nullptr));
+    FD_HIP(hipDeviceSynchronize());
+    p->u_split = packed;
+    p->u_inv_scale = 1.0f / wscale;
+    p->u_split_bytes = (unsigned)(set_floats * sizeof(float));
     return FD_OK;
 }
 
@@ -231,6 +254,7 @@ static int build_unit(fd_detector* d, const ParamTable& t, const std::string& na
         FD_TRY(upload(d, uw.data(), uw.size(), &ud));
         u->w_conv2.cin = mid; u->w_conv2.cout = mid; u->w_conv2.cout_pad = cout_pad; u->w_conv2.tile = d->winograd ? d->winograd : 2;
         u->w_conv2.u = ud; u->w_conv2.bias = u->f_conv2.bias; u->w_conv2.relu = 1;
+        if (mid >= 256 && d->winograd_split) FD_TRY(make_wino_split(d, uw, ud, &u->w_conv2));
     }
     u->has_sc = !dim_match;
     if (u->has_sc) {
@@ -284,6 +308,7 @@ static int build(fd_detector* d, const ParamTable& t) {
             d->w_rpn_conv.cin = 1024; d->w_rpn_conv.cout = 512; d->w_rpn_conv.cout_pad = cout_pad;
             d->w_rpn_conv.tile = d->winograd ? d->winograd : 2;
             d->w_rpn_conv.u = ud; d->w_rpn_conv.bias = d->f_rpn_conv.bias; d->w_rpn_conv.relu = 1;
+            if (d->winograd_split) FD_TRY(make_wino_split(d, u, ud, &d->w_rpn_conv));
         }
         const int A = d->prop.num_ratios * d->prop.num_scales;
         const fd_param* wc = t.get("rpn_cls_score_weight", 2ll * A * 512);
@@ -509,9 +534,12 @@ static int run_unit_split(Plan& pl, const Unit& u, const char* name, const void*
     // and the split-K direct kernel is faster)
     const bool wino2 = pl.f32 && !pl.d->layerwise() && pl.d->winograd && u.w_conv2.u && wino_fits(u.w_conv2, n, h, w) &&
                        (h * w > 49 || (long long)n * h * w >= 16384);
+    // split precision: the feature-map layers only (the ROI head's maps give the 36 GEMMs too few rows)
+    const bool wino2s = !pl.f32 && !pl.d->layerwise() && u.w_conv2.u_split && h * w > 49 && wino_fits_split(u.w_conv2, n, h, w);
     float *wino_v = nullptr, *wino_m = nullptr;
-    if (wino2) {
-        const size_t tp = (size_t)wino_patches_padded(n, h, w, u.w_conv2.tile), nb = (size_t)(u.w_conv2.tile + 2) * (u.w_conv2.tile + 2);
+    if (wino2 || wino2s) {
+        const size_t tp = (size_t)wino_patches_padded(n, h, w, u.w_conv2.tile, wino2s ? 256 : 128);
+        const size_t nb = (size_t)(u.w_conv2.tile + 2) * (u.w_conv2.tile + 2);
         wino_v = pl.buf(NB_WINO_V, nb * tp * u.w_conv2.cin);
         wino_m = pl.buf(NB_WINO_M, nb * tp * u.w_conv2.cout);
     }
@@ -556,6 +584,7 @@ static int run_unit_split(Plan& pl, const Unit& u, const char* name, const void*
                 FD_TRY(conv_tail_fused_forward(c2, c3, t1, n, h, w, res, o3, pl.stream, &fused));
             if (!fused) {
                 if (wino2) FD_TRY(wino_conv_forward(u.w_conv2, t1, n, h, w, wino_v, wino_m, t2, pl.stream));
+                else if (wino2s) FD_TRY(wino_conv_forward_split(u.w_conv2, t1, n, h, w, wino_v, wino_m, t2, pl.d->clamped, pl.stream));
                 else FD_TRY(split_conv_forward(c2, t1, n, h, w, nullptr, o2, pl.stream));
                 FD_TRY(split_conv_forward(c3, t2, n, ho, wo, res, o3, pl.stream));
             }
@@ -654,9 +683,11 @@ static int run_graph_split(Plan& pl, const uint8_t* frames, int B, int H, int W,
     // float32 precision: the 3x3 convolution runs in Winograd form (4/9 of the multiplies) unless tensors
     // are inspected layer by layer
     const bool wino = f32 && !layerwise && d->winograd && wino_fits(d->w_rpn_conv, B, fh, fw);
+    const bool winos = !f32 && !layerwise && d->w_rpn_conv.u_split && wino_fits_split(d->w_rpn_conv, B, fh, fw);
     float *wino_v = nullptr, *wino_m = nullptr;
-    if (wino) {
-        const size_t tp = (size_t)wino_patches_padded(B, fh, fw, d->w_rpn_conv.tile), nb = (size_t)(d->w_rpn_conv.tile + 2) * (d->w_rpn_conv.tile + 2);
+    if (wino || winos) {
+        const size_t tp = (size_t)wino_patches_padded(B, fh, fw, d->w_rpn_conv.tile, winos ? 256 : 128);
+        const size_t nb = (size_t)(d->w_rpn_conv.tile + 2) * (d->w_rpn_conv.tile + 2);
         wino_v = pl.buf(NB_WINO_V, nb * tp * d->w_rpn_conv.cin);
         wino_m = pl.buf(NB_WINO_M, nb * tp * d->w_rpn_conv.cout);
     }
@@ -665,6 +696,7 @@ static int run_graph_split(Plan& pl, const uint8_t* frames, int B, int H, int W,
         o1.ysplit = hid;
         o2.y32 = rout;
         if (wino) FD_TRY(wino_conv_forward(d->w_rpn_conv, feat, B, fh, fw, wino_v, wino_m, hid, pl.stream));
+        else if (winos) FD_TRY(wino_conv_forward_split(d->w_rpn_conv, feat_split, B, fh, fw, wino_v, wino_m, hid, d->clamped, pl.stream));
         else FD_TRY(split_conv_forward(f32 ? d->f_rpn_conv : d->s_rpn_conv, feat_split, B, fh, fw, nullptr, o1, pl.stream));
         FD_TRY(split_conv_forward(f32 ? d->f_rpn_out : d->s_rpn_out, hid, B, fh, fw, nullptr, o2, pl.stream));
     }
@@ -859,6 +891,8 @@ int fd_detector_create(fd_ctx* ctx, const fd_param* params, int n_params, const 
         const int v = atoi(e);
         d->winograd = v == 0 ? 0 : (v == 4 ? 4 : 2);          // 1 and 2: F(2x2,3x3)
     }
+    if (const char* e = getenv("FD_WINOGRAD_SPLIT")) d->winograd_split = atoi(e) != 0;
+    if (d->winograd != 4) d->winograd_split = false;
     d->prop = *cfg;
     const int rc = fd::build(d, t);
     if (rc != FD_OK) {

@@ -231,6 +231,116 @@ __global__ __launch_bounds__(256) void wino4_output_kernel(const float* __restri
     }
 }
 
+// The same two transforms for the split-precision path (fd_split.h): activations arrive and leave as fp16 hi+lo
+// pairs (a value is hi + lo, 22 significant bits), the transforms themselves are float32 arithmetic, and the
+// Winograd-domain input V is written as pairs again, for the f16 matrix cores.  |V| can reach 20 times the
+// largest activation of the patch (the row sums of |B^T| are up to 4.5); values beyond the fp16 range are
+// clamped and counted like everywhere else in that path.
+// one thread: one 6x6 patch, 4 consecutive channels (8 bytes of hi halves and 8 of lo halves per pixel)
+__global__ __launch_bounds__(256) void wino4_input_split_kernel(const uint8_t* __restrict__ x, int B, int H, int W, int C,
+                                                               int th, int tw, long long T_pad, uint8_t* __restrict__ V,
+                                                               unsigned* __restrict__ clamped) {
+    const int c4n = C >> 2;
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long t = idx / c4n;
+    const int c = (int)(idx - t * c4n) * 4;
+    if (t >= (long long)B * th * tw) return;
+    const int tx = (int)(t % tw);
+    const int ty = (int)((t / tw) % th);
+    const int b = (int)(t / ((long long)tw * th));
+    const int y0 = 4 * ty - 1, x0 = 4 * tx - 1;
+    const size_t pitch = (size_t)C * 4, coff = split_offset(c);
+    f32x4 r[6][6];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        f32x4 d[6];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            const int yy = y0 + i, xx = x0 + j;
+            d[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if ((unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W) {
+                const uint8_t* q = x + (((size_t)b * H + yy) * W + xx) * pitch + coff;
+                const f16x4 hi = *reinterpret_cast<const f16x4*>(q), lo = *reinterpret_cast<const f16x4*>(q + 64);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) d[i][e] = (float)hi[e] + (float)lo[e];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 6; ++i) r[i][j] = wino_dot(W4_BT[i], d);
+    }
+    const size_t plane = (size_t)T_pad * pitch;
+    uint8_t* o = V + (size_t)t * pitch + coff;
+    unsigned bad = 0;
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            const f32x4 v = wino_dot(W4_BT[j], r[i]);
+            f16x4 hi, lo;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                _Float16 hh, ll;
+                split_f32(v[e], hh, ll, bad);
+                hi[e] = hh; lo[e] = ll;
+            }
+            *reinterpret_cast<f16x4*>(o + (i * 6 + j) * plane) = hi;
+            *reinterpret_cast<f16x4*>(o + (i * 6 + j) * plane + 64) = lo;
+        }
+    split_report(clamped, bad);
+}
+
+// one thread: one patch (4x4 outputs), 4 consecutive output channels; M is float32, y a split tensor
+__global__ __launch_bounds__(256) void wino4_output_split_kernel(const float* __restrict__ M, int B, int H, int W, int Cout,
+                                                                int th, int tw, long long T_pad,
+                                                                const float* __restrict__ bias, int relu,
+                                                                uint8_t* __restrict__ y, unsigned* __restrict__ clamped) {
+    const int c4n = Cout >> 2;
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long t = idx / c4n;
+    const int c = (int)(idx - t * c4n) * 4;
+    if (t >= (long long)B * th * tw) return;
+    const int tx = (int)(t % tw);
+    const int ty = (int)((t / tw) % th);
+    const int b = (int)(t / ((long long)tw * th));
+    const size_t plane = (size_t)T_pad * Cout;
+    const float* p = M + (size_t)t * Cout + c;
+    f32x4 s[4][6];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        f32x4 m[6];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) m[i] = *reinterpret_cast<const f32x4*>(p + (i * 6 + j) * plane);
+#pragma unroll
+        for (int a = 0; a < 4; ++a) s[a][j] = wino_dot(W4_AT[a], m);
+    }
+    const f32x4 bv = bias ? *reinterpret_cast<const f32x4*>(bias + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+    const size_t pitch = (size_t)Cout * 4, coff = split_offset(c);
+    unsigned bad = 0;
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        const int yy = 4 * ty + a;
+        if (yy >= H) continue;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int xx = 4 * tx + q;
+            if (xx >= W) continue;
+            const f32x4 o = wino_dot(W4_AT[q], s[a]) + bv;
+            f16x4 hi, lo;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                _Float16 hh, ll;
+                if (relu) split_f32_relu(o[e], hh, ll, bad);
+                else split_f32(o[e], hh, ll, bad);
+                hi[e] = hh; lo[e] = ll;
+            }
+            uint8_t* dst = y + (((size_t)b * H + yy) * W + xx) * pitch + coff;
+            *reinterpret_cast<f16x4*>(dst) = hi;
+            *reinterpret_cast<f16x4*>(dst + 64) = lo;
+        }
+    }
+    split_report(clamped, bad);
+}
+
 // U[xi = i * n + j][o][c] = (G g G^T)[i][j] of filter (o, c), n = tile + 2, computed in double from the OIHW
 // weights (times out_scale[o] when given) and rounded once to float32.
 // tile 2: G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]];  tile 4: row j = (1, p_j, p_j^2) / prod_{l != j} (p_j - p_l).
@@ -270,9 +380,59 @@ int wino_pack_weights(const float* w_oihw, int cout, int cin, const float* out_s
     return FD_OK;
 }
 
-long long wino_patches_padded(int batch, int h, int w, int tile) {
+long long wino_patches_padded(int batch, int h, int w, int tile, int align) {
     const long long T = (long long)batch * ((h + tile - 1) / tile) * ((w + tile - 1) / tile);
-    return (T + 127) / 128 * 128;
+    return (T + align - 1) / align * align;
+}
+
+static ConvShape wino_gemm_shape(int cin, int cout) {
+    ConvShape s;
+    s.cin = cin; s.cout = cout; s.kh = 1; s.kw = 1; s.kwp = 1; s.stride = 1; s.pad = 0;
+    return s;
+}
+
+size_t wino_split_weight_floats(int cin, int cout) { return wino_gemm_shape(cin, cout).packed_floats(); }
+
+int wino_pack_weights_split(const float* u_dev, int cin, int cout, int cout_pad, float wscale, void* packed,
+                            hipStream_t stream) {
+    FD_REQUIRE(u_dev && packed && cin % 32 == 0 && cout > 0 && cout <= cout_pad, "wino_pack_weights_split: bad arguments");
+    const ConvShape s = wino_gemm_shape(cin, cout);
+    for (int xi = 0; xi < 36; ++xi)
+        FD_TRY(pack_conv_weights_split(u_dev + (size_t)xi * cout_pad * cin, cin, s, nullptr, wscale,
+                                       static_cast<float*>(packed) + (size_t)xi * s.packed_floats(), stream));
+    return FD_OK;
+}
+
+bool wino_fits_split(const WinoConvParams& p, int batch, int h, int w) {
+    const long long T_pad = wino_patches_padded(batch, h, w, 4, 256);
+    return p.u_split && p.tile == 4 && p.cin % 32 == 0 && p.cout % 32 == 0 && 36 * T_pad * p.cin * 4 < (1ll << 31) &&
+           36 * T_pad * (long long)p.cout * 4 < (1ll << 33) && 36 * T_pad < (1ll << 29) &&
+           36ll * p.u_split_bytes < (1ll << 31);
+}
+
+int wino_conv_forward_split(const WinoConvParams& p, const void* x_split, int batch, int h, int w, void* v_ws, float* m_ws,
+                            void* y_split, unsigned* clamped, hipStream_t stream) {
+    FD_REQUIRE(x_split && y_split && v_ws && m_ws && wino_fits_split(p, batch, h, w),
+               "winograd convolution (split precision): bad arguments or sizes");
+    const int th = (h + 3) / 4, tw = (w + 3) / 4;
+    const long long T = (long long)batch * th * tw, T_pad = wino_patches_padded(batch, h, w, 4, 256);
+    {
+        ProfScope scope(stream, "wino_input", 0.0, 4.0 * p.cin * ((double)batch * h * w + 36.0 * T));
+        const long long items = T * (p.cin / 4);
+        hipLaunchKernelGGL(wino4_input_split_kernel, dim3((unsigned)ceil_div(items, 256)), dim3(256), 0, stream,
+                           static_cast<const uint8_t*>(x_split), batch, h, w, p.cin, th, tw, T_pad,
+                           static_cast<uint8_t*>(v_ws), clamped);
+        FD_LAUNCH_CHECK();
+    }
+    FD_TRY(gemm_split_batched(v_ws, p.u_split, p.u_split_bytes, p.u_inv_scale, 36, (int)T_pad, p.cin, p.cout, m_ws, stream));
+    {
+        ProfScope scope(stream, "wino_output", 0.0, 4.0 * p.cout * (36.0 * T + (double)batch * h * w));
+        const long long items = T * (p.cout / 4);
+        hipLaunchKernelGGL(wino4_output_split_kernel, dim3((unsigned)ceil_div(items, 256)), dim3(256), 0, stream, m_ws, batch,
+                           h, w, p.cout, th, tw, T_pad, p.bias, p.relu, static_cast<uint8_t*>(y_split), clamped);
+        FD_LAUNCH_CHECK();
+    }
+    return FD_OK;
 }
 
 bool wino_fits(const WinoConvParams& p, int batch, int h, int w) {

@@ -101,3 +101,40 @@ def test_winograd_operator_against_float64(b, h, w, cin, cout, relu, form):
     assert e_d <= 3e-6, e_d
     # F(2x2): transforms of additions only; F(4x4): fractional entries up to 3.4, about three times the noise
     assert e_w <= (max(4 * e_d, 2e-6) if form == "winograd" else max(8 * e_d, 5e-6)), (e_w, e_d)
+
+
+def test_split_precision_winograd_against_float64_and_the_direct_form(monkeypatch):
+    """precision="f16x3" runs the RPN's 3x3 convolution and those of the 256-channel stage as F(4x4, 3x3) on
+    fp16 hi+lo pairs (FD_WINOGRAD_SPLIT=0: direct).  The RPN layer against float64 arithmetic on the pass's own
+    input, next to the direct split-precision kernel, and the stage-3 feature map of both forms against each
+    other; nothing may be clamped."""
+    from facedetection_amd.detection import Detector
+    from facedetection_amd import synthetic
+    params = synthetic.synthetic_params(0)
+    w = torch.from_numpy(np.asarray(params["rpn_conv_3x3_weight"], dtype=np.float32)).double()
+    bias = torch.from_numpy(np.asarray(params["rpn_conv_3x3_bias"], dtype=np.float32)).double()
+    wo = torch.from_numpy(np.concatenate([np.asarray(params["rpn_cls_score_weight"], dtype=np.float32).reshape(-1, 512),
+                                          np.asarray(params["rpn_bbox_pred_weight"], dtype=np.float32).reshape(-1, 512)])).double()
+    bo = torch.from_numpy(np.concatenate([np.asarray(params["rpn_cls_score_bias"], dtype=np.float32),
+                                          np.asarray(params["rpn_bbox_pred_bias"], dtype=np.float32)])).double()
+    rng = np.random.default_rng(8)
+    frames = rng.integers(0, 256, size=(2, 333, 517, 3), dtype=np.uint8)
+    errs, feats = {}, {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("FD_WINOGRAD_SPLIT", mode)
+        det = Detector("synthetic:0", 0, own_context=True, precision="f16x3", on_clamp="raise")
+        det.keep_tensors(True, production=True)
+        try:
+            det.forward(frames)
+            assert det.clamped_values() == 0
+            feats[mode] = det.tensor("feat")
+            feat = torch.from_numpy(feats[mode]).double().permute(0, 3, 1, 2)
+            hid = torch.relu(torch.nn.functional.conv2d(feat, w, bias, padding=1))
+            ref = torch.nn.functional.conv2d(hid, wo[:, :, None, None], bo).permute(0, 2, 3, 1).numpy()
+            errs[mode] = float(np.abs(det.tensor("rpn_out") - ref).max()) / float(np.abs(ref).max())
+        finally:
+            det.close()
+    assert errs["0"] <= 5e-6, errs
+    assert errs["1"] <= 6 * max(errs["0"], 5e-7), errs
+    scale = float(np.abs(feats["0"]).max())
+    assert float(np.abs(feats["1"] - feats["0"]).max()) <= 1.5e-5 * scale
