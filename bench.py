@@ -374,8 +374,8 @@ def main():
             "pipeline_tflops": round(GFLOP_PER_FRAME * fps / 1e3, 3),
             "pipeline_frac": round(GFLOP_PER_FRAME * fps / 1e3 / peak, 4),
         }
-        # The float32 pass runs the 3x3 convolutions of the 256-channel stage and of the RPN in Winograd
-        # F(2x2, 3x3) form (4/9 of the multiplies).  Kernel rows and `achieved` count the FLOPs a kernel
+        # Both passes run the wide stride-1 3x3 convolutions (RPN, 256-channel stage; float32 also the
+        # 128-channel stage) in Winograd F(4x4, 3x3) form (1/4 of the multiplies).  Kernel rows and `achieved` count the FLOPs a kernel
         # EXECUTES; pipeline_tflops counts the layer definitions' FLOPs (the direct form, the figure the
         # metric's 354.5 GFLOP per frame stands for).  The executed total is reported next to it.
         executed = sum(r["flops"] for r in iso_rows) / args.frames / 1e9
