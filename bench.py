@@ -439,10 +439,13 @@ def main():
                        "height": H, "width": W,
                        "rpn_pre_nms_top_n": 1000, "rpn_post_nms_top_n": 10, "rpn_min_size": 50,
                        "weights": "seeded random (synthetic:0)", "detections_in_last_step": n_boxes,
-                       "convolution_forms": ("every layer a float32 convolution of the reference's graph; the stride-1 3x3 "
-                                             "layers with 128 or more channels and the RPN's 3x3 run as Winograd "
-                                             "F(4x4,3x3) in float32 (FD_WINOGRAD=%s), the rest direct; the measured error "
-                                             "against float64 is in accuracy_vs_float64"
+                       "convolution_forms": (("the RPN's 3x3 layer and the stride-1 3x3 layers of the 256-channel stage run as "
+                                              "Winograd F(4x4,3x3) on fp16 hi+lo pairs (FD_WINOGRAD=%s), the rest direct"
+                                              if split_head else
+                                              "every layer a float32 convolution of the reference's graph; the stride-1 3x3 "
+                                              "layers with 128 or more channels and the RPN's 3x3 run as Winograd "
+                                              "F(4x4,3x3) in float32 (FD_WINOGRAD=%s), the rest direct; the measured error "
+                                              "against float64 is in accuracy_vs_float64")
                                              % os.environ.get("FD_WINOGRAD", "4")),
                        "frames_start": "pinned host memory (PCIe upload timed)" if args.from_host else "HBM",
                        "library_build": _lib.lib().fd_build_id().decode("ascii")},
