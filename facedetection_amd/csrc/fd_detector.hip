@@ -245,7 +245,7 @@ static int build_unit(fd_detector* d, const ParamTable& t, const std::string& na
     // 427 with the 128-channel stage as well); with F(2x2,3x3) (4/9 of the multiplies, tensors 4x) the
     // 128-channel stage would lose.  At 64 channels the GEMMs are two K-steps long and the transforms cost more
     // than the multiplies saved.  FD_WINO_MIN_MID overrides the channel count (measurements).
-    static const int wino_min_mid = getenv("FD_WINO_MIN_MID") ? atoi(getenv("FD_WINO_MIN_MID")) : (d->winograd == 4 ? 128 : 256);
+    const int wino_min_mid = getenv("FD_WINO_MIN_MID") ? atoi(getenv("FD_WINO_MIN_MID")) : (d->winograd == 4 ? 128 : 256);
     if (stride == 1 && mid >= wino_min_mid) {
         std::vector<float> uw;
         int cout_pad = 0;
@@ -829,7 +829,8 @@ static int frames_per_pass(const fd_detector* d, int batch, int H, int W) {
     const long long h2 = (H - 1) / 2 + 1, w2 = (W - 1) / 2 + 1;      // stem (7x7, stride 2, pad 3)
     const long long h4 = (h2 - 1) / 2 + 1, w4 = (w2 - 1) / 2 + 1;    // max-pool (3x3, stride 2, pad 1)
     long long per_frame = std::max(h2 * w2 * FILTERS[0], h4 * w4 * FILTERS[1]) * 4;
-    per_frame = std::max(per_frame, (long long)d->prop.post_nms_top_n * POOLED * POOLED * FILTERS[4] * 4);
+    // ROI head: the pooled maps (7x7, 1024 channels) are its largest tensor; 4x4 maps of 2048 channels follow
+    per_frame = std::max(per_frame, (long long)d->prop.post_nms_top_n * POOLED * POOLED * FILTERS[3] * 4);
     long long lim = std::max(1ll, ((1ll << 31) - 1) / per_frame);
     if (const char* e = getenv("FD_F32_PASS_FRAMES"))
         if (atoi(e) > 0) lim = std::min<long long>(lim, atoi(e));
