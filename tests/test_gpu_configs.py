@@ -83,30 +83,31 @@ def test_dense_crowd_settings(params):
 
 
 def test_micro_batch_beyond_31_bit_offsets_matches_default_path(params):
-    """16 frames of 1080p make the stage-1 tensors larger than 2^31 bytes, which moves those
-    layers from the buffer-addressed kernels to the pointer-addressed ones.  The graph outputs
-    must agree with the same frames run in two micro-batches of 8 (different kernels, same
-    arithmetic up to summation order)."""
+    """18 frames of 1080p make the stem output and the stage-1 tensors larger than 2^31 bytes (2.39 GB; 16 frames
+    are 2.12 GB and still fit), which moves those layers of the f16x3 pass from the buffer-addressed kernels to the
+    pointer-addressed ones.  The graph outputs must agree with the same frames run as two calls of 9 (different
+    kernels, same arithmetic up to summation order)."""
     from facedetection_amd.detection import Detector
     from facedetection_amd.synthetic import synthetic_image
-    frames = np.stack([synthetic_image(1080, 1920, seed=100 + s) for s in range(16)])
+    base = [synthetic_image(1080, 1920, seed=100 + s) for s in range(6)]
+    frames = np.stack([np.roll(base[s % 6], 53 * (s // 6), axis=1) for s in range(18)])
     det = Detector(params, 0)
     try:
         big = det.forward(frames)
-        halves = [det.forward(frames[i:i + 8]) for i in (0, 8)]
-        dets16 = det.detect_batch(frames)
-        dets8 = det.detect_batch(frames[:8]) + det.detect_batch(frames[8:])
+        halves = [det.forward(frames[i:i + 9]) for i in (0, 9)]
+        dets18 = det.detect_batch(frames)
+        dets9 = det.detect_batch(frames[:9]) + det.detect_batch(frames[9:])
     finally:
         det.close()
     R = 10
     for k, tol in ((0, 0.05), (1, 1e-5), (2, 1e-4)):
         ref = np.concatenate([h[k] for h in halves])
         if k == 0:                                    # rois carry the batch index of their own call
-            ref[8 * R:, 0] += 8
+            ref[9 * R:, 0] += 9
         assert big[k].shape == ref.shape
         assert np.abs(big[k] - ref).max() <= tol, (k, np.abs(big[k] - ref).max())
-    assert len(dets16) == 16
-    for a, b in zip(dets16, dets8):
+    assert len(dets18) == 18
+    for a, b in zip(dets18, dets9):
         assert a.shape == b.shape
         assert np.abs(a[:, 4] - b[:, 4]).max(initial=0) <= 1e-5 and np.abs(a[:, :4] - b[:, :4]).max(initial=0) <= 1.0
 
