@@ -13,7 +13,9 @@ import sys
 
 def layer_list(B, H=1080, W=1920, R=10, mode="f16x3", tile=4):
     """Convolution launches of one forward pass in issue order: (name, M, N, K, FLOPs executed).
-    mode "f16x3": the stem runs fused with the max-pool and each unit of the 64-channel stage is one kernel;
+    mode "f16x3": the stem runs fused with the max-pool, each unit of the 64-channel stage is one kernel, and (tile 4)
+    the RPN's 3x3 layer and the stride-1 3x3 layers of the 256-channel stage are one batched Winograd GEMM launch
+    each, rows padded to whole 256-row tiles;
     mode "f32": fused stem, the 3x3 + 1x1 tail of each 64-channel unit is one kernel, and the stride-1 3x3
     layers from 128 channels on (256 with tile 2) and the RPN's are one batched Winograd GEMM launch each
     ((tile + 2)^2 GEMMs over the tile x tile patches: 1/4 of the direct FLOPs with tile 4, 4/9 with tile 2,
@@ -24,7 +26,8 @@ def layer_list(B, H=1080, W=1920, R=10, mode="f16x3", tile=4):
         ho, wo = (h + 2 * p - k) // s + 1, (w + 2 * p - k) // s + 1
         if wino:
             t = n * ((h + tile - 1) // tile) * ((w + tile - 1) // tile)
-            tp = (t + 127) // 128 * 128
+            align = 256 if mode == "f16x3" else 128
+            tp = (t + align - 1) // align * align
             nb = (tile + 2) ** 2
             layers.append((name + "w", nb * tp, cout, cin, 2.0 * nb * tp * cout * cin))
         else:
@@ -37,7 +40,7 @@ def layer_list(B, H=1080, W=1920, R=10, mode="f16x3", tile=4):
     cin = 64
     for s in range(4):
         if s == 3:
-            conv("rpn3x3", B, h, w, 1024, 512, 3, 1, 1, wino=(mode == "f32"))
+            conv("rpn3x3", B, h, w, 1024, 512, 3, 1, 1, wino=(mode == "f32" or (mode == "f16x3" and tile == 4)))
             conv("rpnout", B, h, w, 512, 72, 1, 1, 0)
             n, h, w = B * R, 7, 7
         else:
@@ -50,6 +53,7 @@ def layer_list(B, H=1080, W=1920, R=10, mode="f16x3", tile=4):
                 conv(nm + "_sc", n, h, w, cin, cout, 1, st, 0)
             conv(nm + "_c1", n, h, w, cin, mid, 1, 1, 0)
             wino = mode == "f32" and st == 1 and mid >= (128 if tile == 4 else 256) and (h * w > 49 or n * h * w >= 16384)
+            wino = wino or (mode == "f16x3" and tile == 4 and st == 1 and mid >= 256 and h * w > 49)
             h2, w2 = conv(nm + "_c2", n, h, w, mid, mid, 3, st, 1, wino=wino)
             conv(nm + "_c3", n, h2, w2, mid, cout, 1, 1, 0)
             if mid == 64 and st == 1 and mode != "layers":

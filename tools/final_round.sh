@@ -18,4 +18,9 @@ timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d $OUT/kt2 -- py
 cd $R
 python3 tools/conv_layer_report.py $(ls $OUT/kt2/*/*kernel_trace.csv | head -1) 16 f32 > $OUT/layers_f32.txt 2>&1 || true
 rm -rf $OUT/kt2
+cd /tmp
+timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d $OUT/kt3 -- python3 $R/bench.py --precision f16x3 --streams 1 --frames 16 --steps 1 --warmup 1 --no-cpu-baseline --no-profile --check-frames 0 --no-split-record > $OUT/b16s.json 2> $OUT/b16s.err
+cd $R
+python3 tools/conv_layer_report.py $(ls $OUT/kt3/*/*kernel_trace.csv | head -1) 16 f16x3 > $OUT/layers_f16x3.txt 2>&1 || true
+rm -rf $OUT/kt3
 echo final round done

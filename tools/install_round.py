@@ -12,7 +12,9 @@ src, dst = os.path.join(ROOT, "gpurun_out", tag), os.path.join(ROOT, "profiles")
 for name in ("kernel_stats.csv", "bench.json", "bench_under_rocprof.json", "pmc_traffic.json", "bench_two_streams.json",
              "frontend.json", "frontend_128.json"):
     shutil.copy(os.path.join(src, name), os.path.join(dst, "%s_%s" % (tag, name)))
-shutil.copy(os.path.join(src, "layers_f32.txt"), os.path.join(dst, "%s_layers_f32.txt" % tag))
+for name in ("layers_f32.txt", "layers_f16x3.txt"):
+    if os.path.exists(os.path.join(src, name)):
+        shutil.copy(os.path.join(src, name), os.path.join(dst, "%s_%s" % (tag, name)))
 for a, b in (("cfg_split.txt", "configs_f16x3.json"), ("cfg_f32.txt", "configs_f32.json")):
     line = [l for l in open(os.path.join(src, a)) if l.startswith("{")][-1]
     open(os.path.join(dst, "%s_%s" % (tag, b)), "w").write(line)
