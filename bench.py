@@ -214,6 +214,8 @@ def main():
     ap.add_argument("--from-host", action="store_true",
                     help="frames start in pinned host memory and are uploaded inside the timed region "
                          "(PCIe-inclusive rate; the default keeps them resident in HBM as the metric is defined)")
+    ap.add_argument("--no-direct-record", action="store_true",
+                    help="skip the sub-record of the float32 pass with every 3x3 layer as a direct convolution")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="skip the per-kernel HIP-event timing")
     ap.add_argument("--rehearse", action="store_true",
@@ -397,11 +399,35 @@ def main():
                   "gbs": round(r["bytes"] / (r["ms"] * 1e-3) / 1e9, 1)} for r in sorted(iso_rows, key=lambda r: -r["ms"])]
         return roof, table
 
+    def measure_direct():
+        """The float32 pass with every 3x3 layer in its direct form (FD_WINOGRAD=0; the form is chosen when a
+        detector is created, hence a second detector): one warm-up step, then K timed steps between barriers."""
+        old = os.environ.get("FD_WINOGRAD")
+        os.environ["FD_WINOGRAD"] = "0"
+        try:
+            direct = FramePipeline("synthetic:0", local, streams=1, precision="f32")
+        finally:
+            if old is None:
+                del os.environ["FD_WINOGRAD"]
+            else:
+                os.environ["FD_WINOGRAD"] = old
+        try:
+            direct.detect_device(frames, B, streams=1)
+            barrier()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                direct.detect_device(frames, B, streams=1)
+            barrier()
+            return max_over_ranks(time.perf_counter() - t0)
+        finally:
+            direct.close()
+
     head = measure(args.precision, args.streams)
     # the same pass with micro-batches alternating over two streams (reported beside the headline: kernels
     # of the two streams overlap, so per-kernel durations there say nothing about a kernel's own roofline)
     head2 = measure(args.precision, 2) if (args.two_streams and args.streams == 1 and n_streams >= 2) else None
     sub = measure("f16x3", args.split_streams) if do_split else None
+    direct_elapsed = measure_direct() if (do_split and not args.no_direct_record) else None
 
     # hand-off (untimed): per-frame detection lists gathered in global frame order
     outs = head["outs"]
@@ -458,6 +484,16 @@ def main():
             line["two_streams"] = {"value": round(total_frames / head2["elapsed"], 3), "unit": "frames/s",
                                    "ms_per_step": round(1000.0 * head2["elapsed"] / args.steps, 3), "streams": 2,
                                    "dtype": line["dtype"]}
+        if direct_elapsed:
+            line["f32_direct_convolutions"] = {
+                "value": round(total_frames / direct_elapsed, 3), "unit": "frames/s",
+                "ms_per_step": round(1000.0 * direct_elapsed / args.steps, 3), "streams": 1, "dtype": "f32",
+                "pipeline_tflops": round(GFLOP_PER_FRAME * total_frames / direct_elapsed / 1e3, 3),
+                "pipeline_frac": round(GFLOP_PER_FRAME * total_frames / direct_elapsed / 1e3 / PEAK_FP32_MATRIX_TFLOPS, 4),
+                "note": "the headline pass with FD_WINOGRAD=0: every 3x3 layer as a direct float32 convolution "
+                        "(%.1f GFLOP executed per frame: pipeline_tflops are executed FLOPs here), for readers who want the "
+                        "headline without the Winograd form"
+                        % GFLOP_PER_FRAME}
         acc = None
         if do_split and args.check_frames > 0:
             acc = accuracy_vs_float64(pipe, frames, min(args.check_frames, args.frames))

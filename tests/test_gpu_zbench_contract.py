@@ -54,6 +54,9 @@ def test_bench_prints_one_json_line_with_the_contract_fields():
     assert s["max_abs_score_err_vs_f64"] <= 1e-4 and s["max_box_err_px"] <= 0.5
     assert s["clamped_values"] == 0 and s["clamped_values_last_timed_step"] == 0
     _check_roofline(s["roofline"])
+    # the same float32 pass without the Winograd form of the wide 3x3 layers, reported next to the headline
+    dc = d["f32_direct_convolutions"]
+    assert dc["dtype"] == "f32" and 0 < dc["value"] <= d["value"] * 1.05
     c = d["cpu_baseline"]
     for key in ("value", "unit", "cores", "kind", "sample"):
         assert key in c, key
