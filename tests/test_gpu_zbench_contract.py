@@ -26,7 +26,7 @@ def _check_roofline(r):
 
 def test_bench_prints_one_json_line_with_the_contract_fields():
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--frames", "16", "--steps", "1", "--warmup", "1",
-                          "--check-frames", "1"], cwd=ROOT, capture_output=True, text=True, timeout=900)
+                          "--check-frames", "1", "--direct-record"], cwd=ROOT, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.strip()]
     assert len(lines) == 1, out.stdout[-2000:]

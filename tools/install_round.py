@@ -10,7 +10,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1]
 src, dst = os.path.join(ROOT, "gpurun_out", tag), os.path.join(ROOT, "profiles")
 for name in ("kernel_stats.csv", "bench.json", "bench_under_rocprof.json", "pmc_traffic.json", "bench_two_streams.json",
-             "frontend.json", "frontend_128.json"):
+             "frontend.json", "frontend_128.json", "bench_direct.json"):
     shutil.copy(os.path.join(src, name), os.path.join(dst, "%s_%s" % (tag, name)))
 for name in ("layers_f32.txt", "layers_f16x3.txt"):
     if os.path.exists(os.path.join(src, name)):
@@ -28,6 +28,8 @@ for name in ("bench.json", "bench_under_rocprof.json"):
           d["f16x3"]["roofline"]["isolated"]["frac"], "| cpu", d["cpu_baseline"]["value"])
 d = json.load(open(os.path.join(dst, "%s_bench_two_streams.json" % tag)))
 print("two streams", d["value"], d["two_streams"]["value"])
+d = json.load(open(os.path.join(dst, "%s_bench_direct.json" % tag)))
+print("direct convolutions", d["value"], d["f32_direct_convolutions"])
 print(open(os.path.join(dst, "%s_frontend.json" % tag)).read()[:800])
 print(open(os.path.join(dst, "%s_frontend_128.json" % tag)).read()[:500])
 for b in ("configs_f16x3.json", "configs_f32.json"):

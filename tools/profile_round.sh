@@ -22,3 +22,4 @@ rm -rf $OUT/pmc_fetch $OUT/pmc_write $OUT/kt
 timeout -k 10 600 python3 bench.py > $OUT/bench.json 2> $OUT/bench.err
 cat $OUT/pmc_summary.txt
 timeout -k 10 600 python3 bench.py --two-streams --no-split-record --no-cpu-baseline > $OUT/bench_two_streams.json 2> $OUT/bench2.err
+timeout -k 10 600 python3 bench.py --direct-record --no-split-record --no-cpu-baseline > $OUT/bench_direct.json 2> $OUT/bench3.err
