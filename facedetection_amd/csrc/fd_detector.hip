@@ -24,7 +24,7 @@ struct Unit {
     ConvParams conv1, conv2, conv3, sc;
     SplitConvParams s_conv1, s_conv2, s_conv3, s_sc;   // split (f16x3) operands
     SplitConvParams f_conv1, f_conv2, f_conv3, f_sc;   // float32 operands on the same kernels
-    WinoConvParams w_conv2;                            // conv2 in Winograd form (float32 precision; wide stride-1 layers only)
+    WinoConvParams w_conv2;                            // conv2 in Winograd form (wide stride-1 layers only; both precisions)
     const float *bn1_scale = nullptr, *bn1_shift = nullptr;   // the unit's input BatchNorm (device)
     bool has_sc = false;
 };
@@ -52,8 +52,8 @@ struct fd_detector {
     fd::ConvParams rpn_conv, rpn_out;
     fd::SplitConvParams s_conv0, s_rpn_conv, s_rpn_out;
     fd::SplitConvParams f_rpn_conv, f_rpn_out, f_conv0;
-    fd::WinoConvParams w_rpn_conv;       // the RPN's 3x3 convolution in Winograd form (float32 precision)
-    int winograd = 4;                    // float32 precision: Winograd tile of the long-K 3x3 layers, 4 = F(4x4,3x3),
+    fd::WinoConvParams w_rpn_conv;       // the RPN's 3x3 convolution in Winograd form (both precisions)
+    int winograd = 4;                    // Winograd tile of the wide 3x3 layers, 4 = F(4x4,3x3),
                                          // 2 = F(2x2,3x3), 0 = direct (environment variable FD_WINOGRAD)
     bool winograd_split = true;          // f16x3 precision: F(4x4,3x3) for the RPN and the 256-channel stage when
                                          // `winograd` is 4 (environment variable FD_WINOGRAD_SPLIT=0: direct)
@@ -530,7 +530,7 @@ static int run_unit_split(Plan& pl, const Unit& u, const char* name, const void*
     float* t1 = pl.buf(NB_T1, (size_t)n * h * w * mid);
     float* t2 = pl.buf(NB_T2, (size_t)n * ho * wo * mid);
     const float* res = xraw;
-    // (on the ROI head's 4x4 maps only with many rois: a few dozen rois leave the 16 GEMMs a handful of tiles,
+    // (on the ROI head's 4x4 maps only with many rois: a few dozen rois leave the batched GEMMs a handful of tiles,
     // and the split-K direct kernel is faster)
     const bool wino2 = pl.f32 && !pl.d->layerwise() && pl.d->winograd && u.w_conv2.u && wino_fits(u.w_conv2, n, h, w) &&
                        (h * w > 49 || (long long)n * h * w >= 16384);
@@ -680,7 +680,7 @@ static int run_graph_split(Plan& pl, const uint8_t* frames, int B, int H, int W,
     const int A = d->prop.num_ratios * d->prop.num_scales;
     float* hid = pl.buf(NB_RPN_HID, (size_t)B * fh * fw * 512);
     float* rout = pl.buf(NB_RPN_OUT, (size_t)B * fh * fw * 6 * A);
-    // float32 precision: the 3x3 convolution runs in Winograd form (4/9 of the multiplies) unless tensors
+    // the 3x3 convolution runs in Winograd form (a quarter of the multiplies with F(4x4,3x3)) unless tensors
     // are inspected layer by layer
     const bool wino = f32 && !layerwise && d->winograd && wino_fits(d->w_rpn_conv, B, fh, fw);
     const bool winos = !f32 && !layerwise && d->w_rpn_conv.u_split && wino_fits_split(d->w_rpn_conv, B, fh, fw);

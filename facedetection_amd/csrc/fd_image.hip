@@ -88,9 +88,10 @@ __global__ __launch_bounds__(256) void resize_linear_u8_kernel(const uint8_t* __
 // channel, and the row value is one 16-bit dot product; the 12 output bytes leave as one 12-byte
 // store (consecutive lanes write consecutive addresses).  (One unaligned 8-byte LDS read per window
 // instead of three aligned dwords gives the same bytes but runs 1.5x slower.)
-// The band is walked along x by ONE workgroup on purpose: the RZ_TY destination rows of a band are
-// one contiguous piece of memory, so all partial cache lines between neighbouring tiles are
-// completed by the same workgroup, in the same L2, a few microseconds apart.  With neighbouring
+// The band is walked along x by one workgroup, or by 2, 4 or 8 that are neighbours in the launch order and
+// therefore run in the same XCD at about the same time (small launches: see the host code), on purpose: the
+// RZ_TY destination rows of a band are one contiguous piece of memory, so all partial cache lines between
+// neighbouring tiles are completed in the same L2, a few microseconds apart.  With neighbouring
 // tiles on different workgroups (round-robin over the XCDs, i.e. different L2s) the stores ran at
 // a third of the rate (ablation: 110 us for loads + stores against 73 us for the loads alone).
 // Arithmetic is that of resize_linear_u8_kernel, bit for bit.

@@ -1,26 +1,27 @@
-// 3x3 stride-1 convolution by Winograd's minimal filtering F(2x2, 3x3) in float32, for the long-K
-// layers of the float32 path (the RPN's 3x3 convolution, reference: code/detection/symbol/
-// faster_rcnn.py:85-87).  A 2x2 block of outputs is computed from its 4x4 input patch d and the
-// filter g as
+// 3x3 stride-1 convolution by Winograd's minimal filtering, for the wide 3x3 layers of the network (the RPN's
+// 3x3 convolution, reference: code/detection/symbol/faster_rcnn.py:85-87, and the stride-1 3x3 layers of the
+// bottleneck units, faster_rcnn.py:41-43).  A tile x tile block of outputs is computed from its
+// (tile + 2) x (tile + 2) input patch d and the filter g as
 //     Y = A^T [ (G g G^T) .* (B^T d B) ] A
-// with 16 multiplies per channel pair instead of 36; summed over input channels the element-wise
-// products become 16 independent GEMMs  M[xi] = V[xi] U[xi]^T  (rows: patches, K: input channels),
-// which run on the fp32 matrix cores through the ordinary 1x1 convolution kernel, launched once
-// for all 16.  Three kernels:
-//     wino_input_kernel    x [B][H][W][C]            -> V [16][T_pad][C]        (HBM-bound)
-//     batched GEMM         V, U [16][cout_pad][C]    -> M [16][T_pad][cout]     (matrix-bound, 4/9 of the direct FLOPs)
-//     wino_output_kernel   M                         -> y [B][H][W][cout] (+ bias, ReLU)   (HBM-bound)
-// The transform matrices hold only 0, +-1 (and +-1/2 in G, applied to the weights in double on the
-// host), so the transforms are additions; measured against float64 the result carries about twice
-// the rounding noise of a direct float32 convolution (rms 4.8e-7 against 2.1e-7 of the output rms at
-// K = 9216).
-// F(4x4, 3x3) (tile = 4) computes a 4x4 block of outputs from a 6x6 patch with 36 multiplies per channel pair
-// instead of 144: 36 GEMMs over a quarter as many patches, and Winograd-domain tensors 2.25x the size of the
-// plain ones instead of 4x.  With the textbook interpolation points 0, +-1, +-2 its transforms amplify
-// rounding errors about six times more than F(2x2)'s; the points used here, 0, +-5/8, +-3/2 (all transform
-// entries stay exact binary fractions), bring that to about three times (simulated with float32 transforms and
-// sequential float32 accumulation over 1024 channels: rms error 2.5e-6 of the output rms against 5.7e-6 for the
-// textbook points, 0.9e-6 for F(2x2) and 1.5e-6 for the direct sum over 9216 products).
+// with n^2 = (tile + 2)^2 multiplies per channel pair instead of 9 tile^2; summed over input channels the
+// element-wise products become n^2 independent GEMMs  M[xi] = V[xi] U[xi]^T  (rows: patches, K: input channels),
+// which run on the matrix cores through the ordinary 1x1 convolution kernel, launched once for all of them.
+// Three kernels:
+//     input transform      x [B][H][W][C]              -> V [n^2][T_pad][C]        (HBM-bound)
+//     batched GEMM         V, U [n^2][cout_pad][C]     -> M [n^2][T_pad][cout]     (matrix-bound)
+//     output transform     M                           -> y [B][H][W][cout] (+ bias, ReLU)   (HBM-bound)
+// F(2x2, 3x3) (tile = 2): 16 GEMMs, 4/9 of the direct FLOPs, Winograd-domain tensors 4x the plain ones.  The
+// transform matrices hold only 0, +-1 (and +-1/2 in G, applied to the weights in double on the host), so the
+// transforms are additions.
+// F(4x4, 3x3) (tile = 4, the detector's default): 36 GEMMs over a quarter as many patches, 1/4 of the direct
+// FLOPs, Winograd-domain tensors 2.25x the plain ones.  With the textbook interpolation points 0, +-1, +-2 its
+// transforms amplify rounding errors about six times more than F(2x2)'s; the points used here, 0, +-5/8, +-3/2
+// (all transform entries stay exact binary fractions), bring that to about three times (simulated with float32
+// transforms and sequential float32 accumulation over 1024 channels: rms error 2.5e-6 of the output rms against
+// 5.7e-6 for the textbook points, 0.9e-6 for F(2x2) and 1.5e-6 for the direct sum over 9216 products; measured on
+// the GPU on the RPN layer's shape with non-negative inputs: 2.3e-6, 0.8e-6 for F(2x2), 1.2e-6 direct).
+// Float32 form (FD_PRECISION_F32) and split-precision form (FD_PRECISION_F16X3, tile 4 only: activations and
+// the Winograd-domain input as fp16 hi+lo pairs, transforms in float32, GEMMs on the f16 matrix cores).
 #include "fd_conv_split.h"
 #include "fd_split.h"
 

@@ -222,8 +222,11 @@ typedef struct fd_param {
 int fd_detector_create(fd_ctx* ctx, const fd_param* params, int n_params, const fd_proposal_cfg* cfg,
                        fd_detector** out);
 void fd_detector_destroy(fd_detector* det);
-/* Arithmetic of the convolutions.  Both accumulate in float32 on the matrix cores.
- *   FD_PRECISION_F32   float32 operands (v_mfma_f32_32x32x2_f32): an fmaf chain.
+/* Arithmetic of the convolutions.  Both accumulate in float32 on the matrix cores.  In both, the RPN's 3x3
+ * convolution and the wide stride-1 3x3 layers of the bottleneck units are computed in Winograd F(4x4,3x3)
+ * form (a quarter of the multiplies; same end-to-end error against float64 as the direct form, see
+ * fd_conv2d_winograd); environment variable FD_WINOGRAD=0, read by fd_detector_create, keeps every layer direct.
+ *   FD_PRECISION_F32   float32 operands (v_mfma_f32_16x16x4_f32): the reference's arithmetic.
  *   FD_PRECISION_F16X3 every float32 operand is split exactly into two fp16 numbers
  *                      (hi + lo, ~22 significant bits) and each product is formed as
  *                      hi*hi + hi*lo + lo*hi on the f16 matrix cores: float32-grade results
