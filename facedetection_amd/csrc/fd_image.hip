@@ -70,9 +70,9 @@ __global__ __launch_bounds__(256) void resize_linear_u8_kernel(const uint8_t* __
 
 // ---------------------------------------------------------------------------------
 // The same resize for 3-channel frames with the source staged through LDS.  A workgroup owns a
-// band of RZ_TY destination rows and walks it in tiles of RZ_TX pixels.  For every tile the two tap
-// rows of each destination row (16 staged rows; rows between the taps of a strong reduction are never
-// touched), cut to the columns the tile's taps span (about RZ_TX / fx + 2 pixels), are fetched by LDS-DMA
+// band of RZ_TY destination rows and walks it in tiles of RZ_TX pixels (128 x 8 or 256 x 4, chosen by the
+// host code).  For every tile the two tap rows of each destination row (2 RZ_TY staged rows; rows between
+// the taps of a strong reduction are never touched), cut to the columns the tile's taps span (about RZ_TX / fx + 2 pixels), are fetched by LDS-DMA
 // (`buffer_load_dwordx4 ... lds`): whole aligned 16-byte chunks of every source row, consecutive
 // lanes on consecutive chunks, so each row segment is one coalesced burst and every source byte is
 // fetched once per tile instead of once per tap and channel with single-byte loads; chunks past the
@@ -95,8 +95,7 @@ __global__ __launch_bounds__(256) void resize_linear_u8_kernel(const uint8_t* __
 // tiles on different workgroups (round-robin over the XCDs, i.e. different L2s) the stores ran at
 // a third of the rate (ablation: 110 us for loads + stores against 73 us for the loads alone).
 // Arithmetic is that of resize_linear_u8_kernel, bit for bit.
-constexpr int RZ_TX = 128, RZ_TY = 8;
-constexpr int RZ_ROUNDS = 8;          // DMA rounds of 256 chunks per tile: up to 32 KB of staged rows (2 KB per row)
+constexpr int RZ_ROUNDS = 8;          // DMA rounds of 256 chunks per tile: up to 32 KB of staged rows
 
 struct Resize3Args {
     const uint8_t* src;
@@ -141,7 +140,7 @@ __device__ __forceinline__ unsigned mulhi_u24(unsigned x, unsigned y) {
     return r;
 }
 
-template <bool AREA2, bool REVERSE>
+template <bool AREA2, bool REVERSE, int RZ_TX, int RZ_TY>
 __global__ __launch_bounds__(256) void resize3_lds_kernel(Resize3Args a) {
 #if defined(__HIP_DEVICE_COMPILE__)
     extern __shared__ __attribute__((aligned(16))) uint8_t rz_lds[];
@@ -187,23 +186,26 @@ __global__ __launch_bounds__(256) void resize3_lds_kernel(Resize3Args a) {
     // staging buffer), because tile j + S - 1's is written while slower waves may still be reading tile
     // j - 1's; columns past the image repeat its last one, so a table is always full
     auto col_taps = [&](int j) {
-        if (tid >= RZ_TX) return;
-        const int dx = min(j * RZ_TX + tid, dw - 1);
-        int2 e;
-        if (AREA2) {
-            e = make_int2(2 * dx, 0);
-        } else {
-            const Tap2 t = linear_tap(dx, a.scale_x, sw);
-            e = make_int2(t.s0, t.w0 | (t.w1 << 16));
+#pragma unroll
+        for (int c = tid; c < RZ_TX; c += 256) {
+            const int dx = min(j * RZ_TX + c, dw - 1);
+            int2 e;
+            if (AREA2) {
+                e = make_int2(2 * dx, 0);
+            } else {
+                const Tap2 t = linear_tap(dx, a.scale_x, sw);
+                e = make_int2(t.s0, t.w0 | (t.w1 << 16));
+            }
+            // entry of column dx at (dx % 4) * (RZ_TX / 4) + dx / 4: the lanes of a wave, which own consecutive
+            // 4-pixel groups, then read consecutive 8-byte entries for each of their 4 pixels (stored in column
+            // order the reads of a wave would be 32 bytes apart and hit 4 of the 32 LDS banks)
+            coltab[(j & tmask) * RZ_TX + (c & 3) * (RZ_TX / 4) + (c >> 2)] = e;
         }
-        // entry of column dx at (dx % 4) * (RZ_TX / 4) + dx / 4: the lanes of a wave, which own consecutive
-        // 4-pixel groups, then read consecutive 8-byte entries for each of their 4 pixels (stored in column
-        // order the reads of a wave would be 32 bytes apart and hit 4 of the 32 LDS banks)
-        coltab[(j & tmask) * RZ_TX + (tid & 3) * (RZ_TX / 4) + (tid >> 2)] = e;
     };
-    // row taps of the band, by the threads the column taps leave idle
-    if (tid >= RZ_TX && tid - RZ_TX < RZ_TY) {
-        const int dy = min(dy0 + tid - RZ_TX, dh - 1);
+    // row taps of the band, by the threads the column taps leave idle (if any)
+    constexpr int ROW_T0 = RZ_TX + RZ_TY <= 256 ? RZ_TX : 0;      // first of the RZ_TY threads that compute them
+    if (tid >= ROW_T0 && tid - ROW_T0 < RZ_TY) {
+        const int dy = min(dy0 + tid - ROW_T0, dh - 1);
         int4 e;
         if (AREA2) {
             e = make_int4(2 * dy, 2 * dy + 1, 0, 0);
@@ -211,7 +213,7 @@ __global__ __launch_bounds__(256) void resize3_lds_kernel(Resize3Args a) {
             const Tap2 t = linear_tap(dy, a.scale_y, sh);
             e = make_int4(t.s0, t.s1, t.w0, t.w1);
         }
-        rowtab[tid - RZ_TX] = e;
+        rowtab[tid - ROW_T0] = e;
     }
     col_taps(j0);
     if (S > 2 && ntiles > j0 + 1) col_taps(j0 + 1);
@@ -259,7 +261,7 @@ __global__ __launch_bounds__(256) void resize3_lds_kernel(Resize3Args a) {
     const unsigned bz = (unsigned)rt.z << 12, bw = (unsigned)rt.w << 12;     // row weights (<= 2^11) as 24-bit factors
 
     // a wave whose rows lie inside the band issues one store per tile when rows are 4-byte aligned
-    const int st = (2 * wave < ny && a.dst_aligned) ? 1 : 0;
+    const int st = ((wave * 64) / GX < ny && a.dst_aligned) ? 1 : 0;       // the wave's first row
     int slot = 0;                                               // j % S
     for (int j = j0; j < ntiles; ++j) {
         if (S == 1) {
@@ -461,14 +463,23 @@ int fd_resize_cvt_u8(fd_ctx* ctx, const uint8_t* src, int batch, int src_h, int 
                         (double)batch * channels * ((double)src_h * src_w + (double)dst_h * dst_w));
     // 3-channel frames take the LDS-staged kernel whenever two tiles' source rectangles fit in LDS (any
     // scale from enlargements down to about 1/6); the per-pixel kernel is the general fallback.
-    static_assert(fd::RZ_TX / 4 * fd::RZ_TY == 256, "one 4-pixel group of a tile per thread");
+    // Tile of a workgroup: tx x ty destination pixels, one 4-pixel group per thread (tx / 4 * ty = 256).  256 x 4 for
+    // moderate reductions of wide frames: row segments twice as long per burst (3 DMA rounds per tile instead of 4 at
+    // 1080p -> 562x1000, half as many partial cache lines between tiles): 106-113 us against 111-114 us on 64 frames,
+    // the same on 128.  128 x 8 otherwise: a strong reduction (4K -> 562x1000) stages the same number of chunks
+    // either way and then the column taps, computed once per tile and shared by its rows, cost twice as much per
+    // pixel on the flatter tile (40.5 against 38 us on 16 frames; 512 x 2 was slower everywhere).
+    // FD_RESIZE_TILE=128|256 overrides (measurements).
+    static const int env_tile = getenv("FD_RESIZE_TILE") ? atoi(getenv("FD_RESIZE_TILE")) : 0;
+    const int tx = env_tile == 256 || env_tile == 128 ? env_tile : ((scale_x < 3.0 && dst_w >= 512) ? 256 : 128);
+    const int ty = 1024 / tx;
     static const bool allow_lds = !(getenv("FD_RESIZE_LDS") && atoi(getenv("FD_RESIZE_LDS")) == 0);
     if (channels == 3 && allow_lds && (size_t)src_h * src_w * 3 < (1ull << 31) && batch <= 65535) {
         fd::Resize3Args a;
         a.src = src; a.dst = dst; a.scale_x = scale_x; a.scale_y = scale_y;
         a.sh = src_h; a.sw = src_w; a.dh = dst_h; a.dw = dst_w;
-        a.max_rows = 2 * fd::RZ_TY;                              // the two tap rows of every destination row
-        const int max_cols = std::min(src_w, (int)std::ceil(fd::RZ_TX * scale_x) + 3);
+        a.max_rows = 2 * ty;                              // the two tap rows of every destination row
+        const int max_cols = std::min(src_w, (int)std::ceil(tx * scale_x) + 3);
         a.pitch = ((max_cols * 3 + 15 + 8) + 15) / 16 * 16;     // worst lead + the taps' 8-byte window, in whole chunks
         const int cpr = a.pitch / 16;
         const int chunks = a.max_rows * cpr;
@@ -483,7 +494,7 @@ int fd_resize_cvt_u8(fd_ctx* ctx, const uint8_t* src, int batch, int src_h, int 
         static const int env_stages = getenv("FD_RESIZE_STAGES") ? atoi(getenv("FD_RESIZE_STAGES")) : 0;
         static const int env_xcd = getenv("FD_RESIZE_XCD") ? atoi(getenv("FD_RESIZE_XCD")) : 1;
         a.stages = env_stages >= 1 && env_stages <= 3 ? env_stages : 1;
-        const size_t tables = (a.stages == 1 ? 2 : 4) * fd::RZ_TX * sizeof(int2) + fd::RZ_TY * sizeof(int4);
+        const size_t tables = (a.stages == 1 ? 2 : 4) * tx * sizeof(int2) + ty * sizeof(int4);
         static const int env_xparts = getenv("FD_RESIZE_XPARTS") ? atoi(getenv("FD_RESIZE_XPARTS")) : 0;
         a.xcd_runs = env_xcd ? 1 : 0;
         a.batch = batch;
@@ -491,17 +502,21 @@ int fd_resize_cvt_u8(fd_ctx* ctx, const uint8_t* src, int batch, int src_h, int 
         // (four rounds of the 2048 that are resident at a time): 64 1080p frames take 2 pieces (-2 %: a shorter
         // tail; 4 pieces cost more in per-workgroup set-up than they gain), 16 4K frames 8 (-9 %).
         a.xparts = 1;
-        while (a.xparts < 8 && (long long)fd::ceil_div(dst_h, fd::RZ_TY) * batch * a.xparts < 8192) a.xparts *= 2;
+        while (a.xparts < 8 && (long long)fd::ceil_div(dst_h, ty) * batch * a.xparts < 8192) a.xparts *= 2;
         if (env_xparts >= 1 && env_xparts <= 8) a.xparts = env_xparts;
         const size_t smem = a.stages * (size_t)a.buf_bytes + tables;
         // chunk -> row by multiplication is exact for chunk indices below 2^20 / cpr and needs cpr >= 2
         if (smem <= 64 * 1024 && cpr >= 2 && chunks <= fd::RZ_ROUNDS * 256 && chunks + 256 <= (1 << 20) / cpr &&
             (size_t)dst_h * dst_w * 3 < (1ull << 31) && dst_h < (1 << 23) && dst_w < (1 << 23) &&
-            (long long)fd::ceil_div(dst_h, fd::RZ_TY) * batch * a.xparts < (1ll << 31) - 8) {
-            const long long nwork = (long long)fd::ceil_div(dst_h, fd::RZ_TY) * batch * a.xparts;
+            (long long)fd::ceil_div(dst_h, ty) * batch * a.xparts < (1ll << 31) - 8) {
+            const long long nwork = (long long)fd::ceil_div(dst_h, ty) * batch * a.xparts;
             dim3 grid((unsigned)((nwork + 7) / 8 * 8));
             const hipStream_t st = fd::as_stream(stream);
-#define FD_RZ(A2, REV) hipLaunchKernelGGL((fd::resize3_lds_kernel<A2, REV>), grid, dim3(256), smem, st, a)
+#define FD_RZ(A2, REV)                                                                                       \
+    do {                                                                                                     \
+        if (tx == 256) hipLaunchKernelGGL((fd::resize3_lds_kernel<A2, REV, 256, 4>), grid, dim3(256), smem, st, a); \
+        else hipLaunchKernelGGL((fd::resize3_lds_kernel<A2, REV, 128, 8>), grid, dim3(256), smem, st, a);   \
+    } while (0)
             if (area2) { if (reverse_channels) FD_RZ(true, true); else FD_RZ(true, false); }
             else { if (reverse_channels) FD_RZ(false, true); else FD_RZ(false, false); }
 #undef FD_RZ
