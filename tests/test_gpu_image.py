@@ -57,6 +57,25 @@ def test_resize_lds_kernel_shapes(shape, fx, fy):
     np.testing.assert_array_equal(ops.resize_bilinear(img, fx, fy), orz.resize_linear_u8(img, fx, fy))
 
 
+@pytest.mark.parametrize("seed", range(6))
+def test_resize_random_shapes_and_factors(seed):
+    """Random frame sizes, batch sizes and factors, drawn so that both tile shapes of the LDS-staged kernel
+    (256 x 4 for destinations of 512 pixels or more at reductions below 3, 128 x 8 otherwise) and the
+    per-pixel fallback (reductions too strong for the staging buffer) are visited, tiles cut by both edges included."""
+    from facedetection_amd import ops
+    rng = np.random.default_rng(100 + seed)
+    for _ in range(4):
+        h, w = int(rng.integers(33, 700)), int(rng.integers(300, 2300))
+        fx = float(rng.choice([rng.uniform(0.12, 0.34), rng.uniform(0.34, 1.0), rng.uniform(1.0, 1.9)]))
+        fy = float(rng.uniform(0.2, 1.6))
+        b = int(rng.integers(1, 4))
+        batch = rng.integers(0, 256, (b, h, w, 3), dtype=np.uint8)
+        out = ops.resize_bilinear(batch, fx, fy)
+        for i in range(b):
+            np.testing.assert_array_equal(out[i], orz.resize_linear_u8(batch[i], fx, fy),
+                                          err_msg="%d x %d x %d, fx %.4f fy %.4f" % (b, h, w, fx, fy))
+
+
 def test_resize_of_a_batch_slice_with_channel_swap():
     """A batch that starts at an address that is not 16-byte aligned (a slice of a larger tensor
     offset by one row of an odd-sized image), with the BGR -> RGB swap of the command-line loop."""
