@@ -70,3 +70,27 @@ def test_asking_for_more_gpus_than_visible_fails_loudly():
                          capture_output=True, text=True, timeout=300,
                          env={k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")})
     assert out.returncode == 2 and out.stdout.strip() == "" and "GPU(s) visible" in out.stderr
+
+
+def test_one_rank_under_the_distributed_launcher_over_rccl():
+    """The launch path of the multi-GPU runs with a single rank: torch.distributed.run starts bench.py, the process
+    group comes up on the "nccl" (RCCL) backend, barriers bracket the timed steps, the detection lists go through the
+    all-gathers of parallel.gather_detections on device tensors, and stdout still carries exactly one JSON line."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
+                          "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
+                          "--gpus", "1", "--frames", "16", "--steps", "1", "--warmup", "1", "--check-frames", "0",
+                          "--no-split-record", "--no-cpu-baseline"], cwd=ROOT, capture_output=True, text=True, timeout=600,
+                         env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip().startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["n_ranks_seen"] == 1 and d["value"] > 0 and d["dtype"] == "f32"
+    assert d["config"]["detections_in_last_step"] >= 0
+    _check_roofline(d["roofline"])
