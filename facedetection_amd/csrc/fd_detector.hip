@@ -57,7 +57,7 @@ struct fd_detector {
                                          // 2 = F(2x2,3x3), 0 = direct (environment variable FD_WINOGRAD)
     bool winograd_split = true;          // f16x3 precision: F(4x4,3x3) for the RPN and the 256-channel stage when
                                          // `winograd` is 4 (environment variable FD_WINOGRAD_SPLIT=0: direct)
-    int precision = FD_PRECISION_F16X3;
+    int precision = FD_PRECISION_F32;      // the reference's arithmetic unless the caller opts into the split form
     const float *bn1_scale = nullptr, *bn1_shift = nullptr;
     const float *w_cls = nullptr, *b_cls = nullptr, *w_box = nullptr, *b_box = nullptr;
     int32_t* nan_flag = nullptr;         // status block on the device: [0] NaN met by the proposal stage,

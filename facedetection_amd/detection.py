@@ -51,7 +51,7 @@ def load_model(model_path, epoch=0):
 class Detector:
     """Faster R-CNN face detector (ResNet-50 backbone) on one MI355X."""
 
-    def __init__(self, model_path, ctx=None, epoch=0, box_f64=True, precision="f16x3", own_context=False,
+    def __init__(self, model_path, ctx=None, epoch=0, box_f64=True, precision="f32", own_context=False,
                  on_clamp="fallback"):
         """``own_context``: give this detector a library context (scratch memory) of its own
         instead of the per-GPU shared one, so that it can run concurrently with other
@@ -92,9 +92,10 @@ class Detector:
             self.set_precision(precision)
 
     def set_precision(self, precision):
-        """"f32": float32 operands on the fp32 matrix cores.  "f16x3" (default): exact two-way
-        fp16 split of both operands, three f16 MFMAs per product, float32 accumulate --
-        float32-grade results, several times faster."""
+        """"f32" (default): float32 operands on the fp32 matrix cores, the reference's arithmetic.
+        "f16x3": exact two-way fp16 split of both operands, three f16 MFMAs per product, float32
+        accumulate -- the same error level against float64 inside the fp16 range, about twice the
+        frame rate; values that leave the range are counted and handled as ``on_clamp`` says."""
         code = {"f32": 0, "f16x3": 1}[precision]
         _lib.check(self._lib.fd_detector_set_precision(self._h, code))
         self.precision = precision

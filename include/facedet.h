@@ -226,13 +226,13 @@ void fd_detector_destroy(fd_detector* det);
  * convolution and the wide stride-1 3x3 layers of the bottleneck units are computed in Winograd F(4x4,3x3)
  * form (a quarter of the multiplies; same end-to-end error against float64 as the direct form, see
  * fd_conv2d_winograd); environment variable FD_WINOGRAD=0, read by fd_detector_create, keeps every layer direct.
- *   FD_PRECISION_F32   float32 operands (v_mfma_f32_16x16x4_f32): the reference's arithmetic.
+ *   FD_PRECISION_F32   float32 operands (v_mfma_f32_16x16x4_f32): the reference's arithmetic.  Default.
  *   FD_PRECISION_F16X3 every float32 operand is split exactly into two fp16 numbers
  *                      (hi + lo, ~22 significant bits) and each product is formed as
  *                      hi*hi + hi*lo + lo*hi on the f16 matrix cores: float32-grade results
  *                      (same error level against a float64 reference) at 16/3 of the rate.
  *                      Activations are clamped to the fp16 range (+-65504); every clamped value
- *                      is counted (fd_detector_status).  Default. */
+ *                      is counted (fd_detector_status).  Opt-in. */
 #define FD_PRECISION_F32 0
 #define FD_PRECISION_F16X3 1
 int fd_detector_set_precision(fd_detector* det, int precision);

@@ -22,7 +22,7 @@ def test_4k_frame_matches_oracle(params):
     from facedetection_amd.synthetic import synthetic_image
     img = np.tile(synthetic_image(1080, 1920, seed=21), (2, 2, 1))          # 2160 x 3840
     assert img.shape == (2160, 3840, 3)
-    det = Detector(params, 0)
+    det = Detector(params, 0, precision="f16x3")
     try:
         dets = det.detect_face(img)
         feat = det.tensor("feat")
@@ -45,7 +45,7 @@ def test_dense_crowd_settings(params):
     from facedetection_amd.symbol.config import config
     from facedetection_amd.synthetic import crowd_image
     img = crowd_image(1080, 1920, seed=2, faces=5000)
-    det = Detector(params, 0)
+    det = Detector(params, 0, precision="f16x3")
     old = (config.TEST.RPN_MIN_SIZE, config.TEST.RPN_PRE_NMS_TOP_N, config.TEST.RPN_POST_NMS_TOP_N)
     config.TEST.RPN_MIN_SIZE, config.TEST.RPN_PRE_NMS_TOP_N, config.TEST.RPN_POST_NMS_TOP_N = 12, 0, 6000
     try:
@@ -91,7 +91,7 @@ def test_micro_batch_beyond_31_bit_offsets_matches_default_path(params):
     from facedetection_amd.synthetic import synthetic_image
     base = [synthetic_image(1080, 1920, seed=100 + s) for s in range(6)]
     frames = np.stack([np.roll(base[s % 6], 53 * (s // 6), axis=1) for s in range(18)])
-    det = Detector(params, 0)
+    det = Detector(params, 0, precision="f16x3")
     try:
         big = det.forward(frames)
         halves = [det.forward(frames[i:i + 9]) for i in (0, 9)]

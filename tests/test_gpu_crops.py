@@ -90,7 +90,7 @@ def test_detect_track_crop_pipeline():
     from facedetection_amd.detection import Detector
     from facedetection_amd.synthetic import synthetic_image
     from facedetection_amd.tracking.sort import Sort
-    det = Detector("synthetic", 0)
+    det = Detector("synthetic", 0, precision="f16x3")
     tracker = Sort()
     try:
         n_ids = 0

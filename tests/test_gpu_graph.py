@@ -40,7 +40,7 @@ def test_single_1080p_frame_replayed():
     from facedetection_amd.detection import Detector
     from facedetection_amd.synthetic import synthetic_image
     frames = [synthetic_image(1080, 1920, seed=70 + s) for s in range(2)]
-    det = Detector("synthetic:0", 0)
+    det = Detector("synthetic:0", 0, precision="f16x3")
     try:
         want = [det.detect_face(f) for f in frames]
         got = [det.detect_face_replayed(f) for f in frames]
@@ -56,7 +56,7 @@ def test_stale_recording_is_refused_and_recorded_again():
     from facedetection_amd.detection import Detector
     from facedetection_amd.synthetic import synthetic_image
     small = synthetic_image(256, 320, seed=80)
-    det = Detector("synthetic:0", 0, own_context=True)       # a context whose buffers start empty
+    det = Detector("synthetic:0", 0, own_context=True, precision="f16x3")       # a context whose buffers start empty
     try:
         want = det.detect_face(small, thresh=0.5)
         rec = det.record(1, 256, 320, thresh=0.5)

@@ -125,7 +125,7 @@ def test_cli_path_resize_then_detect_matches_oracle():
     from oracle import boxes as ob
     from oracle import network as onet
     params = synthetic_params(0)
-    det = Detector(params, 0)
+    det = Detector(params, 0, precision="f16x3")
     config.TEST.RPN_MIN_SIZE = 24               # the CLI default (detection.py:180)
     det.reconfigure()
     try:

@@ -10,13 +10,13 @@ def test_two_streams_match_single_stream_bit_exact():
     from facedetection_amd.pipeline import FramePipeline
     from facedetection_amd.synthetic import synthetic_image
     frames = np.stack([synthetic_image(360, 640, seed=s) for s in range(7)])      # ragged last micro-batch
-    det = Detector("synthetic", 0)
+    det = Detector("synthetic", 0, precision="f16x3")
     try:
         want = det.detect_batch(frames)
     finally:
         det.close()
     for streams in (1, 2, 3):
-        pipe = FramePipeline("synthetic", 0, streams=streams)
+        pipe = FramePipeline("synthetic", 0, streams=streams, precision="f16x3")
         try:
             got = pipe.detect(frames, micro_batch=2)
             again = pipe.detect(frames, micro_batch=3)

@@ -131,5 +131,26 @@ def test_non_finite_parameters_are_refused_at_creation(base, bad):
     w[5, 7, 1, 2] = bad
     q["stage2_unit3_conv2_weight"] = w
     with pytest.raises(_lib.FaceDetError) as e:
-        Detector(q, 0)
+        Detector(q, 0, precision="f16x3")
     assert e.value.code == -5 and "stage2_unit3_conv2_weight" in str(e.value)
+
+
+def test_the_default_is_the_reference_arithmetic(base):
+    """A detector created without a precision argument computes with float32 operands: its rows equal, bit for
+    bit, those of a detector that asks for "f32", and no value is ever counted as clamped."""
+    from facedetection_amd.detection import Detector
+    from facedetection_amd.pipeline import FramePipeline
+    q, img = base
+    a, b = Detector(q, 0), Detector(q, 0, precision="f32")
+    pipe = FramePipeline(q, 0, streams=1)
+    try:
+        assert a.precision == "f32" and pipe.detectors[0].precision == "f32"
+        ra, rb = a.detect_face(img, thresh=0.0), b.detect_face(img, thresh=0.0)
+        rp = pipe.detect(img[None], micro_batch=1, thresh=0.0)[0]
+        np.testing.assert_array_equal(ra, rb)
+        np.testing.assert_array_equal(rp, rb)
+        assert a.clamped_values() == 0
+    finally:
+        a.close()
+        b.close()
+        pipe.close()

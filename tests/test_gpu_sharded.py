@@ -43,7 +43,7 @@ def _worker(rank, world, port, out_dir, case):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         mine = shard_indices(N_FRAMES, rank, world)
-        det = Detector("synthetic:0", 0)
+        det = Detector("synthetic:0", 0, precision="f16x3")
         try:
             frames = torch.from_numpy(np.stack([_frame(i, H, W) for i in mine])).cuda()
             dets, counts, status = det.detect_batch_device(frames, thresh=0.5)
@@ -78,7 +78,7 @@ def test_processes_sharing_one_gpu_gather_what_one_process_detects(tmp_path, cas
     lens = np.load(tmp_path / "len.npy")
     rows = np.load(tmp_path / "rows.npy")
     gathered = np.split(rows, np.cumsum(lens)[:-1])
-    det = Detector("synthetic:0", 0)
+    det = Detector("synthetic:0", 0, precision="f16x3")
     try:
         alone = [det.detect_face(_frame(i, H, W), thresh=0.5) for i in range(N_FRAMES)]
     finally:

@@ -20,7 +20,7 @@ def test_two_threads_two_detectors_with_the_profiler_on(params):
     from facedetection_amd.detection import Detector
     from facedetection_amd.synthetic import synthetic_image
     frames = [np.stack([synthetic_image(256, 320, seed=10 * t + s) for s in range(4)]) for t in range(2)]
-    dets = [Detector(params, 0, own_context=True) for _ in range(2)]
+    dets = [Detector(params, 0, own_context=True, precision="f16x3") for _ in range(2)]
     try:
         expect = [dets[t].detect_batch(frames[t]) for t in range(2)]         # one after the other, no profiler
         results, errors = [None, None], []
@@ -61,7 +61,7 @@ def test_growing_frames_do_not_accumulate_memory(params):
     from facedetection_amd import runtime
     from facedetection_amd.detection import Detector
     from facedetection_amd.synthetic import synthetic_image
-    det = Detector(params, 0, own_context=True)
+    det = Detector(params, 0, own_context=True, precision="f16x3")
     try:
         sizes = [(160 + 92 * i, 256 + 166 * i) for i in range(11)]            # 160x256 ... 1080x1916
         held = []
@@ -69,7 +69,7 @@ def test_growing_frames_do_not_accumulate_memory(params):
             det.detect_face(synthetic_image(h, w, seed=1, faces=1))
             held.append(det._rt.scratch_bytes())
         final = held[-1]
-        det2 = Detector(params, 0, own_context=True)
+        det2 = Detector(params, 0, own_context=True, precision="f16x3")
         try:
             det2.detect_face(synthetic_image(*sizes[-1], seed=1, faces=1))
             fresh = det2._rt.scratch_bytes()                                   # what the last size needs by itself

@@ -16,7 +16,7 @@ SIZES = [(1, 37, 41), (3, 64, 96), (2, 333, 517), (1, 270, 480)]
 def _detector(monkeypatch, mask, keep=False):
     from facedetection_amd.detection import Detector
     monkeypatch.setenv("FD_FUSE_UNITS", str(mask))
-    det = Detector("synthetic:0", 0, own_context=True)
+    det = Detector("synthetic:0", 0, own_context=True, precision="f16x3")
     if keep:
         det.keep_tensors(True)
     return det

@@ -38,7 +38,7 @@ def test_scaled_batch_matches_oracle_loop(params):
     from facedetection_amd.symbol.config import config
     from facedetection_amd.synthetic import synthetic_image
     frames = np.stack([synthetic_image(360, 640, seed=s) for s in (9, 10)])
-    det = Detector(params, 0)
+    det = Detector(params, 0, precision="f16x3")
     config.TEST.RPN_MIN_SIZE = 24
     det.reconfigure()
     try:
@@ -85,7 +85,7 @@ def test_compress_video_keeps_face_stretches(params):
     from oracle import video as ov
     a = synthetic_image(240, 320, seed=1)
     b = np.zeros_like(a)
-    det = Detector(params, 0)
+    det = Detector(params, 0, precision="f16x3")
     try:
         # random weights see "faces" everywhere: put the score threshold between the two frames
         sa = det.detect_face(a, thresh=0.0)[:, 4].max(initial=0.0)

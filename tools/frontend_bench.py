@@ -97,7 +97,7 @@ def main():
     out["crop_16_boxes_to_112x112"] = {"us_per_frame": round(t * 1e6, 1),
                                        "GB_per_s": round((src + 16 * 112 * 112 * 3) / t / 1e9, 2)}
     # the command-line loop end to end on decoded 1080p frames (resize + detect + map back)
-    det = Detector("synthetic:0", 0)
+    det = Detector("synthetic:0", 0, precision="f16x3")
     t = timed(lambda: det.detect_scaled_batch(frames[:8], thresh=0.5), 5)
     out["cli_loop_1080p_batch8"] = {"frames_per_s": round(8 / t, 1)}
     det.close()

@@ -18,9 +18,9 @@ from facedetection_amd.detection import Detector  # noqa: E402
 def main():
     torch.cuda.set_device(0)
     os.environ["FD_FUSE_UNITS"] = "0"
-    ref = Detector("synthetic:0", 0, own_context=True)
+    ref = Detector("synthetic:0", 0, own_context=True, precision="f16x3")
     os.environ["FD_FUSE_UNITS"] = sys.argv[1] if len(sys.argv) > 1 else "3"
-    new = Detector("synthetic:0", 0, own_context=True)
+    new = Detector("synthetic:0", 0, own_context=True, precision="f16x3")
     rng = np.random.default_rng(0)
     worst = 0.0
     for (b, h, w) in [(1, 1080, 1920), (2, 333, 517), (3, 64, 96), (1, 37, 41), (2, 600, 1000)]:

@@ -3,7 +3,7 @@ sys.path.insert(0, os.getcwd())
 from facedetection_amd import profiling
 from facedetection_amd.detection import Detector
 from facedetection_amd.synthetic import synthetic_image
-det = Detector("synthetic:0", 0)
+det = Detector("synthetic:0", 0, precision="f16x3")
 f = det._frames(synthetic_image(1080, 1920, seed=1))
 for _ in range(3): det.detect_batch_device(f)
 torch.cuda.synchronize()

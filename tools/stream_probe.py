@@ -53,7 +53,7 @@ def main():
     torch.cuda.set_device(0)
     frames = make_frames(n, dev, seed=0)
     for S in ss:
-        dets = [Detector("synthetic:0", 0, own_context=True) for _ in range(S)]
+        dets = [Detector("synthetic:0", 0, own_context=True, precision="f16x3") for _ in range(S)]
         if len(sys.argv) > 4 and S > 1:
             streams = [masked_stream(k, S) for k in range(S)]
         else:
