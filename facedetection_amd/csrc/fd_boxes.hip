@@ -1232,8 +1232,12 @@ int fd_nms_f32_noalloc(const float* dets, int n, float thresh, int32_t* keep, in
     int device = -1;
     FD_HIP(hipGetDevice(&device));
     FD_REQUIRE(device >= 0 && device < NOALLOC_MAX_DEVICES, "fd_nms_f32_noalloc: device index %d out of range", device);
-    if (!g_scratch_ptr[device]) FD_TRY(noalloc_init_device(device));       // first call on this GPU
-    unsigned char* base = g_scratch_ptr[device];
+    FD_TRY(noalloc_init_device(device));       // resolves the address on the first call on this GPU (under the mutex)
+    unsigned char* base = nullptr;
+    {
+        std::lock_guard<std::mutex> lock(g_scratch_mu);
+        base = g_scratch_ptr[device];
+    }
     NmsWorkspace<float, uint32_t> w;
     w.mask = reinterpret_cast<uint64_t*>(base);
     w.boxes = reinterpret_cast<float*>(base + NOALLOC_OFF_BOXES);

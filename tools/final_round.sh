@@ -23,4 +23,18 @@ timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d $OUT/kt3 -- py
 cd $R
 python3 tools/conv_layer_report.py $(ls $OUT/kt3/*/*kernel_trace.csv | head -1) 16 f16x3 > $OUT/layers_f16x3.txt 2>&1 || true
 rm -rf $OUT/kt3
+# SQ counters of one float32 micro-batch (one --pmc pass), HBM traffic of the front-end kernels (two passes), and the
+# float32 pass with the frames uploaded from pinned host memory inside the timed region
+cd /tmp
+SHORT="--frames 16 --steps 1 --warmup 1 --no-cpu-baseline --no-profile --check-frames 0 --no-split-record"
+timeout -s KILL 120 rocprofv3 --pmc SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_INSTS_LDS GRBM_GUI_ACTIVE --output-format csv -d $OUT/sq -- python3 $R/bench.py $SHORT > $OUT/sq.json 2> $OUT/sq.err
+cp $(ls $OUT/sq/*/*counter_collection.csv | head -1) $OUT/sq_counters_f32.csv
+rm -rf $OUT/sq
+timeout -s KILL 200 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/rz_fetch -- python3 $R/tools/frontend_bench.py 64 > $OUT/rz_fetch.json 2> $OUT/rz_fetch.err
+timeout -s KILL 200 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/rz_write -- python3 $R/tools/frontend_bench.py 64 > $OUT/rz_write.json 2> $OUT/rz_write.err
+cd $R
+python3 tools/pmc_summary.py $(ls $OUT/rz_fetch/*/*counter_collection.csv | head -1) $(ls $OUT/rz_write/*/*counter_collection.csv | head -1) $OUT/frontend_pmc_traffic.json > $OUT/rz_pmc_summary.txt
+rm -rf $OUT/rz_fetch $OUT/rz_write
+timeout -k 10 400 python3 bench.py --from-host --no-split-record --no-cpu-baseline --no-profile > $OUT/bench_from_host.json 2> $OUT/bench_from_host.err
+python3 tools/sq_summary.py $OUT/sq_counters_f32.csv 14 > $OUT/sq_table.md
 echo final round done

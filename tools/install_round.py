@@ -10,11 +10,31 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1]
 src, dst = os.path.join(ROOT, "gpurun_out", tag), os.path.join(ROOT, "profiles")
 for name in ("kernel_stats.csv", "bench.json", "bench_under_rocprof.json", "pmc_traffic.json", "bench_two_streams.json",
-             "frontend.json", "frontend_128.json", "bench_direct.json"):
+             "frontend.json", "frontend_128.json", "bench_direct.json", "bench_from_host.json", "frontend_pmc_traffic.json"):
     shutil.copy(os.path.join(src, name), os.path.join(dst, "%s_%s" % (tag, name)))
 for name in ("layers_f32.txt", "layers_f16x3.txt"):
     if os.path.exists(os.path.join(src, name)):
         shutil.copy(os.path.join(src, name), os.path.join(dst, "%s_%s" % (tag, name)))
+# SQ-counter table of the float32 pass: header with the command, then the table tools/sq_summary.py printed on the box
+if os.path.exists(os.path.join(src, "sq_table.md")):
+    build = json.load(open(os.path.join(src, "bench.json")))["config"]["library_build"]
+    with open(os.path.join(dst, "%s_sq_counters_f32.md" % tag), "w") as f:
+        f.write("# SQ counters of one float32 pass (16 frames of 1080p, micro-batch 16, warm-up + one step), library build %s\n\n" % build)
+        f.write("Command (one `--pmc` pass, counters only; durations come from separate `--kernel-trace --stats` runs):\n"
+                "`rocprofv3 --pmc SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS "
+                "SQ_INSTS_LDS GRBM_GUI_ACTIVE --output-format csv -- python3 bench.py --frames 16 --steps 1 --warmup 1 --no-cpu-baseline "
+                "--no-profile --check-frames 0 --no-split-record`,\nsummarised by `tools/sq_summary.py` (kernel families summed over their "
+                "launches; the detector's set-up kernels and torch's\nframe-generation kernels are in the list as well).\n\n"
+                "Columns: matrix pipe busy = SQ_VALU_MFMA_BUSY_CYCLES / (1 024 SIMDs x GRBM_GUI_ACTIVE / 8); clock = GRBM_GUI_ACTIVE / 8 /\n"
+                "dispatch duration (meaningful for the long kernels only: the counter window of a short dispatch is longer than the "
+                "dispatch);\nwaves waiting = SQ_WAIT_INST_ANY / SQ_WAVE_CYCLES.\n\n")
+        f.write(open(os.path.join(src, "sq_table.md")).read())
+        f.write("\nReading: the float32 GEMM families and the fused stem keep the fp32 matrix pipes busy 72-75 % of their launches at a\n"
+                "sustained 2.2-2.4 GHz (the f16 kernels of round 1 ran at 1.8 GHz); `roofline.frac` of the dominant kernel is that figure\n"
+                "times the clock ratio.  LDS waits are 1-2 % of wave time: operands arrive by LDS-DMA and fragment reads are conflict-free;\n"
+                "what the waves wait for is the matrix pipe itself (one wave per SIMD and workgroup, two or three workgroups per CU) and,\n"
+                "outside the K loop, the tile's epilogue traffic.  The short-K 1x1 layer on `<128,64,3,4,true,0>` (K = 64) shows what is\n"
+                "left when the K loop is two steps long.\n")
 for a, b in (("cfg_split.txt", "configs_f16x3.json"), ("cfg_f32.txt", "configs_f32.json")):
     line = [l for l in open(os.path.join(src, a)) if l.startswith("{")][-1]
     open(os.path.join(dst, "%s_%s" % (tag, b)), "w").write(line)
@@ -28,6 +48,10 @@ for name in ("bench.json", "bench_under_rocprof.json"):
           d["f16x3"]["roofline"]["isolated"]["frac"], "| cpu", d["cpu_baseline"]["value"])
 d = json.load(open(os.path.join(dst, "%s_bench_two_streams.json" % tag)))
 print("two streams", d["value"], d["two_streams"]["value"])
+d = json.load(open(os.path.join(dst, "%s_bench_from_host.json" % tag)))
+print("from host", d["value"], d["config"]["library_build"])
+d = json.load(open(os.path.join(dst, "%s_frontend_pmc_traffic.json" % tag)))
+print("resize traffic", {k: (v["fetch_bytes_per_launch"], v["write_bytes_per_launch"]) for k, v in d["kernels"].items() if "resize3" in k})
 d = json.load(open(os.path.join(dst, "%s_bench_direct.json" % tag)))
 print("direct convolutions", d["value"], d["f32_direct_convolutions"])
 print(open(os.path.join(dst, "%s_frontend.json" % tag)).read()[:800])
