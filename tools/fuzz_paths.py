@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
-"""One-off robustness run: precision="f32" on random frame sizes and batch sizes, the kernels of an ordinary
-pass (fused stem, fused tails, Winograd layers, three-workgroup tiles) against the layer-by-layer pass of
-the same detector.  Prints the worst relative difference per tensor; exits non-zero above 3e-5.
+"""One-off robustness run on random frame sizes and batch sizes: the kernels of an ordinary pass (fused stem,
+fused tails or whole-unit kernels, Winograd layers, the large tiles) against the layer-by-layer pass of the same
+detector, in either precision.  Prints the worst relative difference per tensor; exits non-zero above 3e-5.
 
-    python tools/fuzz_f32_paths.py [cases=12] [seed=0]
+    python tools/fuzz_paths.py [cases=12] [seed=0] [precision=f32]
 """
 import os
 import sys
@@ -17,8 +17,9 @@ from facedetection_amd.detection import Detector  # noqa: E402
 def main():
     cases = int(sys.argv[1]) if len(sys.argv) > 1 else 12
     rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
-    lay = Detector("synthetic:0", 0, own_context=True, precision="f32")
-    new = Detector("synthetic:0", 0, own_context=True, precision="f32")
+    precision = sys.argv[3] if len(sys.argv) > 3 else "f32"
+    lay = Detector("synthetic:0", 0, own_context=True, precision=precision, on_clamp="raise")
+    new = Detector("synthetic:0", 0, own_context=True, precision=precision, on_clamp="raise")
     lay.keep_tensors(True)
     new.keep_tensors(True, production=True)
     worst = {}
