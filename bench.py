@@ -72,7 +72,9 @@ def pmc_traffic(kernel):
     from facedetection_amd import _lib
     build = _lib.lib().fd_build_id().decode("ascii")
     m = re.match(r"conv_(split|f32|igemm)_(\d+)x(\d+)(_pre|_o\d)?$", kernel)
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic.json")))
+    # (the passes over the front-end benchmark, *_frontend_pmc_traffic.json, do not cover this benchmark's kernels)
+    files = sorted(f for f in glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic.json"))
+                   if "frontend" not in os.path.basename(f))
     if not m or not files:
         return None, "no PMC pass covers this kernel"
     with open(files[-1]) as f:
