@@ -40,6 +40,7 @@ H, W = 1080, 1920
 GFLOP_PER_FRAME = 354.5          # algorithmic, post_nms_top_n = 10 (2 x 177.25 GMAC)
 PEAK_FP32_MATRIX_TFLOPS = 157.3  # v_mfma_f32_32x32x2_f32, dense
 PEAK_F16_MATRIX_TFLOPS = 2500.0  # v_mfma_f32_16x16x32_f16, dense
+PEAK_HBM_GBS = 8000.0            # HBM3E peak
 PROP = dict(pre_nms_top_n=1000, post_nms_top_n=10, nms_thresh=0.7, min_size=50)
 PMC_BATCH = 16                   # default micro-batch; the committed PMC passes are taken at it (16 frames' stage-1
                                  # tensors are the largest the 2^31-byte buffer-addressed kernels reach)
@@ -95,6 +96,31 @@ def pmc_traffic(kernel):
         if want.search(kname):
             return row["hbm_bytes_per_launch"], "HBM bytes per launch from %s (kernel set %s)" % (name, build)
     return None, "%s has no row for this kernel" % name
+
+
+def hbm_whole_pass(fps):
+    """HBM traffic of the whole float32 pass per frame (every kernel, PMC counters: profiles/*pmc_traffic_f32.json,
+    two passes over this benchmark with --no-split-record) times the measured frame rate, against the 8 TB/s peak --
+    the pass as a whole is bound by the fp32 matrix cores, and this says how far from the memory roof it runs.
+    Only quoted when the file was taken on the kernel set of the library that is running."""
+    import glob
+    from facedetection_amd import _lib
+    build = _lib.lib().fd_build_id().decode("ascii")
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic_f32.json")))
+    if not files:
+        return {"bytes_per_frame": None, "note": "no whole-pass PMC file under profiles/"}
+    with open(files[-1]) as f:
+        doc = json.load(f)
+    name = os.path.basename(files[-1])
+    whole = doc.get("whole_run")
+    if doc.get("csrc_sha16") != build or not whole:
+        return {"bytes_per_frame": None,
+                "note": "%s was taken on kernel set %s, the library running is %s" % (name, doc.get("csrc_sha16"), build)}
+    gbs = whole["hbm_bytes_per_frame"] * fps / 1e9
+    return {"bytes_per_frame": whole["hbm_bytes_per_frame"], "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+            "frac": round(gbs / PEAK_HBM_GBS, 4),
+            "note": "PMC bytes of every kernel of the float32 pass per frame (%s, %d frames at micro-batch %d) x frames/s"
+                    % (name, whole["frames"], PMC_BATCH)}
 
 
 def cpu_baseline(budget_s=15.0):
@@ -484,6 +510,8 @@ def main():
         if roof:
             line["roofline"] = roof
             line["kernels_single_stream_step"] = table
+        if not split_head and B == PMC_BATCH:
+            line["hbm_whole_pass"] = hbm_whole_pass(fps)
         if head2:
             line["two_streams"] = {"value": round(total_frames / head2["elapsed"], 3), "unit": "frames/s",
                                    "ms_per_step": round(1000.0 * head2["elapsed"] / args.steps, 3), "streams": 2,

@@ -45,6 +45,11 @@ def test_bench_prints_one_json_line_with_the_contract_fields():
     # definition FLOPs (every layer as a direct convolution) and the FLOPs the kernels executed
     assert 0 < d["roofline"]["executed_gflop_per_frame"] <= 354.5 * 1.02
     assert d["roofline"]["pipeline_executed_frac"] <= d["roofline"]["pipeline_frac"] * 1.02
+    # traffic of the whole float32 pass against the HBM peak: a measurement on this kernel set, or null with the reason
+    h = d["hbm_whole_pass"]
+    assert h["note"] and (h["bytes_per_frame"] is None or
+                          (h["peak"] == 8000.0 and abs(h["frac"] - h["achieved"] / h["peak"]) < 1e-3 and
+                           abs(h["achieved"] - h["bytes_per_frame"] * d["value"] / 1e9) <= 1e-3 * h["achieved"] + 0.1))
     a = d["accuracy_vs_float64"]
     assert a["max_abs_score_err_vs_f64"] <= 1e-4 and a["max_box_err_px"] <= 0.5 and a["clamped_values"] == 0
     s = d["f16x3"]

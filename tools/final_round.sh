@@ -8,6 +8,7 @@ R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/$TAG
 bash tools/profile_round.sh $TAG
 cp $OUT/pmc_traffic.json $R/profiles/${TAG}_pmc_traffic.json
+cp $OUT/pmc_traffic_f32.json $R/profiles/${TAG}_pmc_traffic_f32.json
 bash tools/profile_round.sh $TAG
 timeout -k 10 200 python3 tools/frontend_bench.py 64 > $OUT/frontend.json 2>/dev/null
 timeout -k 10 200 python3 tools/frontend_bench.py 128 > $OUT/frontend_128.json 2>/dev/null

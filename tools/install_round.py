@@ -10,7 +10,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1]
 src, dst = os.path.join(ROOT, "gpurun_out", tag), os.path.join(ROOT, "profiles")
 for name in ("kernel_stats.csv", "bench.json", "bench_under_rocprof.json", "pmc_traffic.json", "bench_two_streams.json",
-             "frontend.json", "frontend_128.json", "bench_direct.json", "bench_from_host.json", "frontend_pmc_traffic.json"):
+             "frontend.json", "frontend_128.json", "bench_direct.json", "bench_from_host.json", "frontend_pmc_traffic.json", "pmc_traffic_f32.json"):
     shutil.copy(os.path.join(src, name), os.path.join(dst, "%s_%s" % (tag, name)))
 for name in ("layers_f32.txt", "layers_f16x3.txt"):
     if os.path.exists(os.path.join(src, name)):

@@ -19,6 +19,14 @@ timeout -s KILL 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_w
 cd $R
 python3 tools/pmc_summary.py $(ls $OUT/pmc_fetch/*/*counter_collection.csv | head -1) $(ls $OUT/pmc_write/*/*counter_collection.csv | head -1) $OUT/pmc_traffic.json > $OUT/pmc_summary.txt
 rm -rf $OUT/pmc_fetch $OUT/pmc_write $OUT/kt
+# the float32 pass alone (warm-up + one step of 16 frames = 32 frames): traffic of the whole pass per frame
+cd /tmp
+SHORT32="--frames 16 --steps 1 --warmup 1 --no-cpu-baseline --no-profile --check-frames 0 --no-split-record"
+timeout -s KILL 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch32 -- python3 $R/bench.py $SHORT32 > $OUT/pmc_fetch32.json 2> $OUT/pmc_fetch32.err
+timeout -s KILL 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write32 -- python3 $R/bench.py $SHORT32 > $OUT/pmc_write32.json 2> $OUT/pmc_write32.err
+cd $R
+python3 tools/pmc_summary.py $(ls $OUT/pmc_fetch32/*/*counter_collection.csv | head -1) $(ls $OUT/pmc_write32/*/*counter_collection.csv | head -1) $OUT/pmc_traffic_f32.json 32 > $OUT/pmc_summary_f32.txt
+rm -rf $OUT/pmc_fetch32 $OUT/pmc_write32
 timeout -k 10 600 python3 bench.py > $OUT/bench.json 2> $OUT/bench.err
 cat $OUT/pmc_summary.txt
 timeout -k 10 600 python3 bench.py --two-streams --no-split-record --no-cpu-baseline > $OUT/bench_two_streams.json 2> $OUT/bench2.err
