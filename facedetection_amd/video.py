@@ -155,6 +155,8 @@ def parse_args(argv=None):
     p.add_argument("--min-size", type=int, default=24, help="the min size of object")
     p.add_argument("--scale", type=int, default=600, help="the scale of shorter edge will be resize to")
     p.add_argument("--max-scale", type=int, default=1000, help="the maximize scale after resize")
+    p.add_argument("--precision", type=str, default="f32", choices=["f32", "f16x3"],
+                   help="arithmetic of the convolutions: float32 operands (the reference's) or the faster fp16 hi+lo split")
     return p.parse_args(argv)
 
 
@@ -163,7 +165,7 @@ def main(argv=None):
     from .symbol.config import config
     args = parse_args(argv)
     raw = tuple(int(v) for v in args.raw_size.lower().split("x")) if args.raw_size else None
-    det = Detector(args.prefix, args.gpu, args.epoch)
+    det = Detector(args.prefix, args.gpu, args.epoch, precision=args.precision)
     config.TEST.RPN_MIN_SIZE = args.min_size            # detection.py:186-188
     config.SCALES = (args.scale,)
     config.MAX_SIZE = args.max_scale
