@@ -113,11 +113,13 @@ inline hipStream_t as_stream(void* s) { return static_cast<hipStream_t>(s); }
 // records one event before and one after the launches it brackets, on the launch stream,
 // and carries the algorithmic FLOPs / bytes of that work.  Inactive scopes cost one branch.
 bool prof_active();
-int prof_open(hipStream_t stream, const char* kernel, double flops, double bytes);
-void prof_close(hipStream_t stream, int token);
+// A token names a record of one profiling session (session number << 32 | record index; negative: none),
+// so a scope that outlives its session cannot write into a record of the next one.
+long long prof_open(hipStream_t stream, const char* kernel, double flops, double bytes);
+void prof_close(hipStream_t stream, long long token);
 struct ProfScope {
     hipStream_t stream;
-    int token;
+    long long token;
     ProfScope(hipStream_t s, const char* kernel, double flops, double bytes)
         : stream(s), token(prof_active() ? prof_open(s, kernel, flops, bytes) : -1) {}
     ~ProfScope() {

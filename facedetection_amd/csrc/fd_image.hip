@@ -277,7 +277,10 @@ __global__ __launch_bounds__(256) void resize3_lds_kernel(Resize3Args a) {
         // store of tile j - 1, or (S = 2) the store of tile j - 1 only.  The loads of the tile ahead and the
         // youngest store may stay in flight, so no tile waits out a write round trip or the prefetch.
         // (A wave that stores byte by byte counts none of its stores: waiting longer is always safe.)
-        wait_vmcnt_upto((S > 2 && j + 1 < ntiles ? rounds : 0) + (j > j0 ? st : 0));
+        // With a single buffer the order is the other way round -- the store of tile j - 1 was issued BEFORE
+        // the loads of tile j -- so the youngest operations are the loads themselves and nothing may stay
+        // in flight.
+        wait_vmcnt_upto(S == 1 ? 0 : (S > 2 && j + 1 < ntiles ? rounds : 0) + (j > j0 ? st : 0));
         __syncthreads();                                        // ... everyone's; the taps written above are visible
         if (S > 1 && j + S - 1 < ntiles) {                      // that buffer was last read while computing tile j - 1
             int ns = slot + S - 1;

@@ -100,6 +100,11 @@ class Detector:
         _lib.check(self._lib.fd_detector_set_precision(self._h, code))
         self.precision = precision
 
+    def _drop_recorded(self):
+        """Recorded passes bake in the proposal settings of the moment they were made."""
+        for rec in self.__dict__.pop("_recorded", {}).values():
+            rec.close()
+
     def _proposal_cfg(self):
         # values are read from the global config when the detector is built or re-configured,
         # like the reference bakes them into its symbol (symbol/faster_rcnn.py:98-102)
@@ -110,10 +115,10 @@ class Detector:
         """Re-read config.TEST.RPN_* (after the caller changed them)."""
         self._cfg = self._proposal_cfg()
         _lib.check(self._lib.fd_detector_set_proposal(self._h, C.byref(self._cfg)))
+        self._drop_recorded()
 
     def close(self):
-        for rec in self.__dict__.pop("_recorded", {}).values():
-            rec.close()
+        self._drop_recorded()
         if getattr(self, "_h", None):
             self._lib.fd_detector_destroy(self._h)
             self._h = None
@@ -277,7 +282,9 @@ class Detector:
         """``detect_face`` through a recorded pass (made on first use for each frame size and setting;
         same results).  For loops over frames of one size, e.g. a video."""
         a = np.asarray(img_np)
-        key = (a.shape[0], a.shape[1], float(nms_thresh), float(thresh), self.precision)
+        cfg = self._cfg
+        key = (a.shape[0], a.shape[1], float(nms_thresh), float(thresh), self.precision,
+               int(cfg.pre_nms_top_n), int(cfg.post_nms_top_n), float(cfg.min_size), float(cfg.nms_thresh))
         cache = self.__dict__.setdefault("_recorded", {})
         for attempt in (0, 1):
             rec = cache.get(key)

@@ -17,20 +17,31 @@ def params():
     return synthetic_params(0)
 
 
-def test_4k_frame_matches_oracle(params):
-    from facedetection_amd.detection import Detector
+@pytest.fixture(scope="module")
+def oracle_4k(params):
+    """The float64 oracle's pass over the 4K test frame (computed once for both precisions)."""
     from facedetection_amd.synthetic import synthetic_image
-    img = np.tile(synthetic_image(1080, 1920, seed=21), (2, 2, 1))          # 2160 x 3840
+    # four different quadrants: a 2 x 2 tiling of one image would give every detection three twins whose
+    # scores differ by rounding noise only, and the order of the rows would be a coin toss
+    q = [synthetic_image(1080, 1920, seed=21 + i) for i in range(4)]
+    img = np.concatenate([np.concatenate(q[:2], axis=1), np.concatenate(q[2:], axis=1)], axis=0)     # 2160 x 3840
+    cfg = dict(pre_nms_top_n=1000, post_nms_top_n=10, nms_thresh=0.7, min_size=50)
+    ref, inter = onet.detect_face(img, params, cfg, dtype=torch.float64, return_all=True)
+    return img, ref, inter
+
+
+@pytest.mark.parametrize("precision", ["f32", "f16x3"])
+def test_4k_frame_matches_oracle(params, oracle_4k, precision):
+    from facedetection_amd.detection import Detector
+    img, ref, inter = oracle_4k
     assert img.shape == (2160, 3840, 3)
-    det = Detector(params, 0, precision="f16x3")
+    det = Detector(params, 0, precision=precision)
     try:
         dets = det.detect_face(img)
         feat = det.tensor("feat")
     finally:
         det.close()
     assert feat.shape == (1, 135, 240, 1024)
-    cfg = dict(pre_nms_top_n=1000, post_nms_top_n=10, nms_thresh=0.7, min_size=50)
-    ref, inter = onet.detect_face(img, params, cfg, dtype=torch.float64, return_all=True)
     # the stage-3 feature map of the ordinary (fused-kernel) pass against the float64 oracle
     ref_feat = inter["feat"].transpose(0, 2, 3, 1)
     assert np.abs(feat - ref_feat).max() / np.abs(ref_feat).max() < 5e-5
@@ -39,19 +50,22 @@ def test_4k_frame_matches_oracle(params):
     assert np.abs(dets[:, :4] - ref[:, :4]).max(initial=0) <= 1.0
 
 
-def test_dense_crowd_settings(params):
+@pytest.mark.parametrize("precision", ["f32", "f16x3"])
+def test_dense_crowd_settings(params, precision):
     """1080p, RPN_MIN_SIZE 12, no pre-NMS cut (97 920 candidates), 6 000 rois into stage 4."""
     from facedetection_amd.detection import Detector
     from facedetection_amd.symbol.config import config
     from facedetection_amd.synthetic import crowd_image
+    from oracle import roipool as orp
     img = crowd_image(1080, 1920, seed=2, faces=5000)
-    det = Detector(params, 0, precision="f16x3")
+    det = Detector(params, 0, precision=precision)
     old = (config.TEST.RPN_MIN_SIZE, config.TEST.RPN_PRE_NMS_TOP_N, config.TEST.RPN_POST_NMS_TOP_N)
     config.TEST.RPN_MIN_SIZE, config.TEST.RPN_PRE_NMS_TOP_N, config.TEST.RPN_POST_NMS_TOP_N = 12, 0, 6000
     try:
         det.reconfigure()
         rois, cls_prob, deltas = det.forward(img)
         rpn_out = det.tensor("rpn_out")
+        feat = det.tensor("feat")
         dets = det.detect_face(img)
     finally:
         config.TEST.RPN_MIN_SIZE, config.TEST.RPN_PRE_NMS_TOP_N, config.TEST.RPN_POST_NMS_TOP_N = old
@@ -72,6 +86,16 @@ def test_dense_crowd_settings(params):
     keep = cboxes.nms(cand, 0.7)[:6000]
     assert len(keep) == 6000, "the stress input should leave at least 6000 proposals"
     np.testing.assert_allclose(rois[:, 1:], boxes[order][keep].astype(np.float32), rtol=1e-6, atol=1e-3)
+    # Stage 4 + classifier at this batch size (faster_rcnn.py:103,137-160; 6 000 rois make the float32 pass take
+    # its many-roi kernels: batched Winograd GEMMs on the 4x4 maps) against the float64 oracle: the first and
+    # last rois and a stride through the middle, pooled by the oracle from the pass's own feature map
+    pick = np.unique(np.concatenate([np.arange(64), np.arange(64, 5936, 46), np.arange(5936, 6000)]))
+    assert pick.size >= 256
+    pooled = orp.roi_pooling(feat.transpose(0, 3, 1, 2), rois[pick], (7, 7), 0.0625)
+    with torch.no_grad():
+        ref_prob, ref_deltas = onet.head(torch.from_numpy(pooled), params, torch.float64)
+    assert np.abs(cls_prob[pick] - ref_prob.numpy()).max() <= 1e-4
+    assert np.abs(deltas[pick] - ref_deltas.numpy()).max() <= 1e-4
     # final detections: sorted, mutually below the NMS threshold, scores from the head
     assert dets.shape[0] > 0 and (np.diff(dets[:, 4]) <= 0).all() and (dets[:, 4] >= 0.8).all()
     again = ob.nms(dets, 0.3) if dets.shape[0] < 3000 else cboxes.nms(dets, 0.3)

@@ -32,7 +32,7 @@ def _free_port():
     return port
 
 
-def _worker(rank, world, port, out_dir, case):
+def _worker(rank, world, port, out_dir, case, precision):
     import torch
     import torch.distributed as dist
     from facedetection_amd.detection import Detector
@@ -43,7 +43,7 @@ def _worker(rank, world, port, out_dir, case):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         mine = shard_indices(N_FRAMES, rank, world)
-        det = Detector("synthetic:0", 0, precision="f16x3")
+        det = Detector("synthetic:0", 0, precision=precision)
         try:
             frames = torch.from_numpy(np.stack([_frame(i, H, W) for i in mine])).cuda()
             dets, counts, status = det.detect_batch_device(frames, thresh=0.5)
@@ -60,8 +60,9 @@ def _worker(rank, world, port, out_dir, case):
         dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("precision", ["f32", "f16x3"])
 @pytest.mark.parametrize("case", ["small", "4k"])
-def test_processes_sharing_one_gpu_gather_what_one_process_detects(tmp_path, case):
+def test_processes_sharing_one_gpu_gather_what_one_process_detects(tmp_path, case, precision):
     import torch.multiprocessing as mp
     from facedetection_amd.detection import Detector
     from facedetection_amd.parallel import feed_tracker
@@ -69,7 +70,7 @@ def test_processes_sharing_one_gpu_gather_what_one_process_detects(tmp_path, cas
     N_FRAMES, WORLD, H, W = CASES[case]
     port = _free_port()
     ctx = mp.get_context("spawn")                 # fresh processes: nothing inherited from this one's GPU state
-    procs = [ctx.Process(target=_worker, args=(r, WORLD, port, str(tmp_path), case)) for r in range(WORLD)]
+    procs = [ctx.Process(target=_worker, args=(r, WORLD, port, str(tmp_path), case, precision)) for r in range(WORLD)]
     for p in procs:
         p.start()
     for p in procs:
@@ -78,7 +79,7 @@ def test_processes_sharing_one_gpu_gather_what_one_process_detects(tmp_path, cas
     lens = np.load(tmp_path / "len.npy")
     rows = np.load(tmp_path / "rows.npy")
     gathered = np.split(rows, np.cumsum(lens)[:-1])
-    det = Detector("synthetic:0", 0, precision="f16x3")
+    det = Detector("synthetic:0", 0, precision=precision)
     try:
         alone = [det.detect_face(_frame(i, H, W), thresh=0.5) for i in range(N_FRAMES)]
     finally:
@@ -100,3 +101,44 @@ def test_processes_sharing_one_gpu_gather_what_one_process_detects(tmp_path, cas
     assert sum(len(a) for a in t_a) > 0
     for a, b in zip(t_a, t_b):
         np.testing.assert_array_equal(np.asarray(a), np.asarray(b))
+
+
+def _nccl_worker(port, out_dir):
+    """One rank on the RCCL backend: the detection tensors stay on the device through gather_detections
+    (count exchange and padded gather as device collectives)."""
+    import torch
+    import torch.distributed as dist
+    from facedetection_amd.detection import Detector
+    from facedetection_amd.parallel import gather_detections
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        det = Detector("synthetic:0", 0)
+        try:
+            frames = torch.from_numpy(np.stack([_frame(i, 360, 640) for i in range(4)])).cuda()
+            dets, counts, status = det.detect_batch_device(frames, thresh=0.5)
+            assert dets.is_cuda and counts.is_cuda
+            out = gather_detections(dets, counts, 0, 1, force_collective=True)
+            plain = gather_detections(dets, counts, 0, 1)
+        finally:
+            det.close()
+        assert len(out) == len(plain) == 4 and sum(len(o) for o in out) > 0
+        for a, b in zip(out, plain):
+            np.testing.assert_array_equal(a, b)
+        np.save(os.path.join(out_dir, "ok.npy"), np.array([len(o) for o in out], dtype=np.int64))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_device_tensors_through_the_rccl_gather(tmp_path):
+    """The device-tensor path of parallel.gather_detections on hardware (backend "nccl" = RCCL), one rank: the
+    collectives run on the GPU and give what the collective-free path gives."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    p = ctx.Process(target=_nccl_worker, args=(_free_port(), str(tmp_path)))
+    p.start()
+    p.join(300)
+    assert p.exitcode == 0, p.exitcode
+    assert np.load(tmp_path / "ok.npy").sum() > 0

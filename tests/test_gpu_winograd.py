@@ -76,7 +76,11 @@ def test_winograd_rpn_convolution_against_float64(monkeypatch):
 
 
 @pytest.mark.parametrize("b,h,w,cin,cout", [(1, 1, 1, 32, 8), (2, 5, 7, 32, 72), (3, 8, 8, 64, 64), (1, 37, 51, 96, 40),
-                                            (2, 68, 120, 256, 256)])
+                                            (2, 68, 120, 256, 256),
+                                            # the ROI head's shape with many rois (4x4 maps, one mostly zero-filled
+                                            # 6x6 patch each, 512 channels): the float32 pass runs it once a call
+                                            # carries 1 024 rois or more
+                                            (1024, 4, 4, 512, 512)])
 @pytest.mark.parametrize("relu", [False, True])
 @pytest.mark.parametrize("form", ["winograd", "winograd4"])
 def test_winograd_operator_against_float64(b, h, w, cin, cout, relu, form):

@@ -57,3 +57,20 @@ def test_no_alloc_nms_equals_the_allocating_entry_point():
         assert rc == 0 and nk == 0
         rc, _, _ = _call(L.fd_nms_f32_noalloc, None, _boxes(4097, 4), 0.5)
         assert rc == -3 and b"4096" in L.fd_last_error()                 # FD_ERR_LIMIT, nothing launched
+
+
+@pytest.mark.parametrize("tag,thresh", [("nms_n1000", 0.7), ("nms_n1000", 0.3), ("nms_n10", 0.3), ("nms_n1", 0.7)])
+def test_no_alloc_nms_against_reference_vectors(tag, thresh):
+    """The no-allocation entry point on its own against keep lists the reference's nms produced
+    (code/detection/symbol/processing.py:114-148; tests/golden/nms.npz, written by tests/golden/make_golden.py)."""
+    import os
+    from facedetection_amd import _lib
+    L = _lib.lib()
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "nms.npz"))
+    dets = np.ascontiguousarray(g[tag + "_dets"], dtype=np.float32)
+    want = g["%s_t%d_keep" % (tag, round(thresh * 10))]
+    with torch.cuda.device(0):
+        rc, keep, nk = _call(L.fd_nms_f32_noalloc, None, dets, thresh)
+    assert rc == 0, L.fd_last_error()
+    assert nk == len(want)
+    np.testing.assert_array_equal(keep, want)
