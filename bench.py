@@ -11,10 +11,11 @@ Frames are sharded by index across ranks (one process per GPU, no data-path coll
 timed region only to exercise the hand-off.  Rank 0 prints ONE JSON line.
 
 The line's headline (`value`, `dtype`, `roofline`) is measured with float32 operands on the fp32
-matrix cores -- the reference's arithmetic.  The same run then times the library's default
-arithmetic (f16x3: every float32 operand as an exact-to-22-bit fp16 hi+lo pair, three f16 MFMAs
-per product) and reports it as the sub-record `f16x3`, together with its measured error against
-the float64 oracle on frames of this benchmark and the number of values it had to clamp.
+matrix cores -- the reference's arithmetic.  After the timed region the same process measures, as
+sub-records under `configs`, the other configurations of the benchmark definition at the same
+precision (single 1080p frame latency, 4K frames, the dense-crowd stress setting) and the
+front-end resize, each HBM-bound stage with its fraction of the HBM peak; `--split-record` adds
+the opt-in f16x3 arithmetic (not the reference's: 22 significant bits, fp16 range) as `f16x3`.
 
 Launching: `python bench.py --gpus N` with N > 1 and no RANK in the environment starts N ranks
 itself (fresh processes, one per GPU, before this process touches a GPU); under
@@ -36,8 +37,36 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-H, W = 1080, 1920
-GFLOP_PER_FRAME = 354.5          # algorithmic, post_nms_top_n = 10 (2 x 177.25 GMAC)
+H, W = 1080, 1920               # the headline's frame size (--height / --width)
+
+
+def gmac_per_frame(height, width, rois=10):
+    """Multiply-accumulates of one frame by the graph's definition (every layer a direct convolution;
+    code/detection/symbol/faster_rcnn.py:107-162): stem 7x7/2, max-pool, bottleneck stages of (3, 4, 6)
+    units to 1024 channels at stride 16, the RPN's 3x3 + 1x1 heads, and per roi the 3 units of stage 4 on a
+    7x7 map plus the two FC layers.  1080p with 10 rois: 177.25 GMAC."""
+    def out(n, k, s, p):
+        return (n + 2 * p - k) // s + 1
+    h, w = out(height, 7, 2, 3), out(width, 7, 2, 3)
+    macs = h * w * 147 * 64
+    h, w = out(h, 3, 2, 1), out(w, 3, 2, 1)
+    cin = 64
+    for s, (units, c) in enumerate(((3, 256), (4, 512), (6, 1024))):
+        mid = c // 4
+        for u in range(units):
+            st = 2 if (u == 0 and s > 0) else 1
+            ho, wo = out(h, 3, st, 1), out(w, 3, st, 1)
+            macs += h * w * cin * mid + ho * wo * 9 * mid * mid + ho * wo * mid * c
+            if u == 0:
+                macs += ho * wo * cin * c
+            h, w, cin = ho, wo, c
+    macs += h * w * (9 * 1024 * 512 + 512 * 72)
+    head = 49 * 1024 * 512 + 16 * 9 * 512 * 512 + 16 * 512 * 2048 + 16 * 1024 * 2048
+    head += 2 * (16 * 2048 * 512 + 16 * 9 * 512 * 512 + 16 * 512 * 2048) + 2048 * 10
+    return (macs + rois * head) / 1e9
+
+
+GFLOP_PER_FRAME = 354.5          # 1080p, post_nms_top_n = 10: 2 x gmac_per_frame(1080, 1920) = 2 x 177.25 GMAC
 PEAK_FP32_MATRIX_TFLOPS = 157.3  # v_mfma_f32_32x32x2_f32, dense
 PEAK_F16_MATRIX_TFLOPS = 2500.0  # v_mfma_f32_16x16x32_f16, dense
 PEAK_HBM_GBS = 8000.0            # HBM3E peak
@@ -142,8 +171,8 @@ def cpu_baseline(budget_s=15.0):
                        % (n, threads, dt))
 
 
-def accuracy_vs_float64(pipe, frames, n_check):
-    """Untimed: the graph outputs of the first `n_check` benchmark frames in both precisions against
+def accuracy_vs_float64(pipe, frames, n_check, precisions=("f32",)):
+    """Untimed: the graph outputs of the first `n_check` benchmark frames in the given precisions against
     oracle.network in float64 on the host.  Score error = max |cls_prob - oracle|; box error = max
     coordinate difference (pixels) of the decoded, clipped class-1 boxes (detection.py:47-49)."""
     from facedetection_amd.synthetic import synthetic_params
@@ -161,7 +190,7 @@ def accuracy_vs_float64(pipe, frames, n_check):
     saved = det.on_clamp
     det.on_clamp = "ignore"                # measure the split arithmetic itself, not its fallback
     try:
-        for prec in ("f32", "f16x3"):
+        for prec in precisions:
             det.set_precision(prec)
             s_err = b_err = 0.0
             clamped = 0
@@ -178,6 +207,147 @@ def accuracy_vs_float64(pipe, frames, n_check):
     return out
 
 
+def _kernel_table(rows, calls=1):
+    """Per-kernel rows of a bracketed run: kernels with FLOPs carry TFLOP/s, every kernel its algorithmic
+    GB/s and that rate as a fraction of the HBM peak (the figure that matters for the memory-bound ones)."""
+    out = []
+    for r in sorted(rows, key=lambda r: -r["ms"]):
+        gbs = r["bytes"] / (r["ms"] * 1e-3) / 1e9 if r["ms"] > 0 else 0.0
+        out.append({"kernel": r["kernel"], "launches": r["launches"] // calls, "ms": round(r["ms"] / calls, 4),
+                    "tflops": round(r["flops"] / (r["ms"] * 1e-3) / 1e12, 3) if r["flops"] else None,
+                    "gbs": round(gbs, 1), "hbm_frac": round(gbs / PEAK_HBM_GBS, 4)})
+    return out
+
+
+HBM_BOUND_KERNELS = ("stage_input", "wino_input", "wino_output", "proposal_decode", "radix_sort", "nms_mask", "nms_reduce",
+                     "roipool", "split_k_finish", "bn_relu_avgpool")
+
+
+def hbm_bound_stages(table):
+    """The memory-bound kernels of a kernel table: algorithmic GB/s against the 8 TB/s HBM peak.  The sort and the
+    NMS kernels are latency-bound at the default 1 000 candidates per frame (small launches); the dense-crowd
+    record shows them at 97 920."""
+    out = {}
+    for r in table:
+        if r["kernel"] in HBM_BOUND_KERNELS:
+            out[r["kernel"]] = {"ms": r["ms"], "launches": r["launches"], "achieved": r["gbs"], "peak": PEAK_HBM_GBS,
+                                "unit": "GB/s", "frac": r["hbm_frac"]}
+    nms = [r for r in table if r["kernel"] in ("nms_mask", "nms_reduce")]
+    if len(nms) == 2:
+        ms = sum(r["ms"] for r in nms)
+        gb = sum(r["gbs"] * r["ms"] for r in nms) / ms if ms > 0 else 0.0
+        out["nms_mask+nms_reduce"] = {"ms": round(ms, 4), "achieved": round(gb, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                                      "frac": round(gb / PEAK_HBM_GBS, 4)}
+    return out
+
+
+def _timed(fn, reps, warm=2, sync_each=False):
+    """Seconds per call of fn on the current stream (the host runs ahead of the GPU unless sync_each)."""
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        fn()
+        if sync_each:
+            torch.cuda.synchronize()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / reps
+
+
+def _bracketed(fn, reps):
+    from facedetection_amd import profiling
+    profiling.begin()
+    for _ in range(reps):
+        fn()
+    torch.cuda.synchronize()
+    return _kernel_table(profiling.end(), reps)
+
+
+def config_records(det, frames, device):
+    """The other configurations of the benchmark definition and the front-end resize, on this GPU, at the
+    headline's precision (untimed with respect to the headline; rank 0 only).  `det` is the headline's
+    detector, `frames` its resident 1080p frames."""
+    from facedetection_amd import ops
+    from facedetection_amd.symbol import processing as P
+    from facedetection_amd.symbol.config import config
+    from facedetection_amd.synthetic import crowd_image, synthetic_image
+    rec = {}
+
+    # configuration 2: one 1080p frame, batch 1, full cascade
+    one = frames[:1]
+    call = lambda: det.detect_batch_device(one)
+    rec["latency_1080p"] = {
+        "ms": round(1e3 * _timed(call, 30, sync_each=True), 3),
+        "ms_back_to_back": round(1e3 * _timed(call, 30), 3), "unit": "ms per frame", "dtype": det.precision,
+        "workload": "one 1080p frame resident in HBM through fd_detect, batch 1 (ms: host waits for every frame; "
+                    "ms_back_to_back: calls queued without waiting)"}
+    table = _bracketed(call, 10)
+    rec["latency_1080p"]["kernel_launch_groups"] = int(sum(r["launches"] for r in table))
+    rec["latency_1080p"]["kernels"] = table[:8]
+
+    # configuration 4's frame size: 4K frames in micro-batches of 4 (their stage-1 tensors are as large as those
+    # of 16 frames of 1080p)
+    q = [synthetic_image(1080, 1920, seed=900 + i) for i in range(4)]
+    k4 = np.concatenate([np.concatenate(q[:2], axis=1), np.concatenate(q[2:], axis=1)], axis=0)
+    f4 = torch.from_numpy(np.stack([np.roll(k4, 97 * i, axis=1) for i in range(8)])).to(device)
+    t = _timed(lambda: [det.detect_batch_device(f4[i:i + 4]) for i in (0, 4)], 3, warm=1)
+    t1 = _timed(lambda: det.detect_batch_device(f4[:1]), 10, sync_each=True)
+    rec["frame_4k"] = {"value": round(8 / t, 2), "unit": "frames/s per GPU", "ms_single_frame": round(1e3 * t1, 3),
+                       "dtype": det.precision, "gflop_per_frame": round(2 * gmac_per_frame(2160, 3840), 1),
+                       "workload": "8 synthetic 2160x3840 frames resident in HBM, micro-batches of 4, full cascade"}
+    del f4
+
+    # front-end resize of the command-line loop (detection.py:63-78, :110): 1080p -> 562 x 1000, 64 frames per launch
+    n_rz = min(64, int(frames.shape[0]))
+    scale = 1000.0 / 1920.0
+    src = frames[:n_rz]
+    small = ops.resize_bilinear(src, scale, scale)
+    moved = src.numel() + small.numel()
+    rows = [r for r in _bracketed(lambda: ops.resize_bilinear(src, scale, scale), 20) if r["kernel"] == "resize_linear_u8"]
+    if rows:
+        us = rows[0]["ms"] * 1e3 / max(1, rows[0]["launches"])
+        gbs = moved / (us * 1e-6) / 1e9
+        rec["frontend_resize"] = {
+            "bound": "hbm", "kernel": "resize_linear_u8", "frames": n_rz, "us_per_launch": round(us, 2),
+            "algorithmic_bytes": int(moved), "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+            "frac": round(gbs / PEAK_HBM_GBS, 4),
+            "workload": "%d frames of 1080x1920x3 uint8 -> %dx%d, OpenCV INTER_LINEAR fixed-point arithmetic; "
+                        "bytes = 3 (H W + h' w') per frame" % (n_rz, small.shape[1], small.shape[2])}
+    del small
+
+    # configuration 5: dense crowd -- every anchor that passes the 12-pixel filter goes into the RPN NMS (no pre-NMS
+    # cut), 6 000 rois into stage 4
+    img = torch.from_numpy(crowd_image(1080, 1920, seed=2, faces=5000)[None]).to(device)
+    saved = (config.TEST.RPN_MIN_SIZE, config.TEST.RPN_PRE_NMS_TOP_N, config.TEST.RPN_POST_NMS_TOP_N)
+    config.TEST.RPN_MIN_SIZE, config.TEST.RPN_PRE_NMS_TOP_N, config.TEST.RPN_POST_NMS_TOP_N = 12, 0, 6000
+    try:
+        det.reconfigure()
+        call = lambda: det.detect_batch_device(img)
+        ms = 1e3 * _timed(call, 5, warm=2, sync_each=True)
+        table = _bracketed(call, 3)
+        dets, n, _ = call()
+        rout = det.tensor("rpn_out")                                  # [1, fh, fw, 72] = bg(12) | fg(12) | deltas(48)
+        fh, fw = rout.shape[1], rout.shape[2]
+        base = P.generate_anchors(16, (0.5, 1, 2), (4, 8, 16, 32))
+        sx, sy = np.meshgrid(np.arange(fw) * 16.0, np.arange(fh) * 16.0)
+        shifts = np.stack([sx.ravel(), sy.ravel(), sx.ravel(), sy.ravel()], axis=1)
+        anchors = (shifts[:, None, :] + base[None, :, :]).reshape(-1, 4).astype(np.float32)
+        boxes = P.clip_boxes(P.bbox_pred(anchors, rout[0, :, :, 24:].reshape(-1, 4)), (1080, 1920))
+        cand = int(((boxes[:, 2] - boxes[:, 0] + 1 >= 12) & (boxes[:, 3] - boxes[:, 1] + 1 >= 12)).sum())
+        rec["dense_crowd"] = {
+            "ms": round(ms, 3), "unit": "ms per frame", "dtype": det.precision, "candidates_into_rpn_nms": cand,
+            "rois_into_stage4": 6000, "detections": int(n[0].item()),
+            "gflop_per_frame": round(2 * gmac_per_frame(1080, 1920, 6000), 1),
+            "workload": "one 1080p frame with 5 000 synthetic 12-40 px faces; RPN_MIN_SIZE 12, no pre-NMS cut, "
+                        "RPN_POST_NMS_TOP_N 6000",
+            "hbm_bound_stages": hbm_bound_stages(table), "kernels": table[:10]}
+    finally:
+        config.TEST.RPN_MIN_SIZE, config.TEST.RPN_PRE_NMS_TOP_N, config.TEST.RPN_POST_NMS_TOP_N = saved
+        det.reconfigure()
+    return rec
+
+
 # ----------------------------------------------------------------------------- launching
 def free_port():
     s = socket.socket()
@@ -187,12 +357,44 @@ def free_port():
     return port
 
 
+def visible_gpu_count():
+    """GPUs this process would see, counted without initialising HIP (torch.cuda.device_count() calls
+    hipGetDeviceCount on ROCm): the visibility variables if set, else the compute nodes the kernel driver
+    lists under /sys/class/kfd (GPU nodes are those with SIMDs)."""
+    import glob
+    nodes = 0
+    for prop in glob.glob("/sys/class/kfd/kfd/topology/nodes/*/properties"):
+        try:
+            with open(prop) as f:
+                fields = dict(line.split()[:2] for line in f if len(line.split()) >= 2)
+            nodes += 1 if int(fields.get("simd_count", "0")) > 0 else 0
+        except (OSError, ValueError):
+            pass
+    for var in ("HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            nodes = min(nodes, len([x for x in v.split(",") if x.strip()]))
+    return nodes
+
+
+def under_profiler():
+    """A profiler's preloaded library has initialised the GPU in this process before main() runs."""
+    return ("rocprof" in os.environ.get("LD_PRELOAD", "").lower()
+            or any(k.startswith(("ROCPROFILER_", "ROCPROF_", "ROCP_")) for k in os.environ))
+
+
 def launch_ranks(args):
     """`--gpus N` without a launcher: start N ranks of this script, one per GPU.  Nothing in this
-    process has touched a GPU (device_count does not initialise the runtime), and the ranks are
-    fresh interpreters, not forks or re-execs of an initialised process."""
+    process has touched a GPU (the devices are counted from the driver's topology files, not through
+    HIP), and the ranks are fresh interpreters started as child processes.  Under a profiler the
+    parent process is already initialised on the GPU, so the self-launcher refuses to run there:
+    profile a single rank, or let torch.distributed.run start the ranks."""
     if not args.rehearse:
-        have = torch.cuda.device_count()
+        if under_profiler():
+            sys.stderr.write("bench.py: --gpus %d under a profiler: this process is already initialised on the GPU and "
+                             "must not start further GPU processes; nothing was run\n" % args.gpus)
+            return 2
+        have = visible_gpu_count()
         if have < args.gpus:
             sys.stderr.write("bench.py: --gpus %d asked for, %d GPU(s) visible on this host; nothing was run\n"
                              % (args.gpus, have))
@@ -237,7 +439,13 @@ def main():
                          "that a kernel trace of the default run holds single-stream launches of the headline kernels only)")
     ap.add_argument("--precision", default="f32", choices=["f32", "f16x3"],
                     help="arithmetic of the HEADLINE: float32 operands (the reference's, default), or the f16x3 split")
-    ap.add_argument("--no-split-record", action="store_true", help="skip the f16x3 sub-record and the accuracy check")
+    ap.add_argument("--height", type=int, default=1080, help="frame height of the headline workload")
+    ap.add_argument("--width", type=int, default=1920, help="frame width of the headline workload")
+    ap.add_argument("--split-record", action="store_true",
+                    help="also time the opt-in f16x3 arithmetic (not the reference's) and report it as the sub-record f16x3")
+    ap.add_argument("--no-split-record", action="store_true", help="(default; kept for older command lines)")
+    ap.add_argument("--no-config-records", action="store_true",
+                    help="skip the sub-records of the other configurations (single-frame latency, 4K, dense crowd, resize)")
     ap.add_argument("--check-frames", type=int, default=2, help="frames compared with the float64 oracle")
     ap.add_argument("--from-host", action="store_true",
                     help="frames start in pinned host memory and are uploaded inside the timed region "
@@ -252,6 +460,9 @@ def main():
                     help="CPU rehearsal of launcher, barriers, timing and gather over gloo; no detector runs")
     args = ap.parse_args()
 
+    global H, W, GFLOP_PER_FRAME
+    H, W = args.height, args.width
+    GFLOP_PER_FRAME = round(2 * gmac_per_frame(H, W, PROP["post_nms_top_n"]), 1)
     if "RANK" not in os.environ and args.gpus > 1:
         sys.exit(launch_ranks(args))
 
@@ -335,7 +546,7 @@ def main():
     from facedetection_amd import _lib, profiling
     from facedetection_amd.pipeline import FramePipeline
 
-    do_split = not args.no_split_record and args.precision == "f32"
+    do_split = args.split_record and not args.no_split_record and args.precision == "f32"
     n_streams = max(args.streams, args.split_streams if do_split else 1, 2 if args.two_streams else 1)
     pipe = FramePipeline("synthetic:0", local, streams=n_streams, precision=args.precision)
     frames = make_frames(args.frames, device, seed=rank)
@@ -403,20 +614,22 @@ def main():
             "flop_per_launch": round(dom["flops"] / dom["launches"]),
             "measured": "HIP events around every launch of this kernel inside the timed region (%d stream%s)"
                         % (m["streams"], "" if m["streams"] == 1 else "s: launches overlap the other stream's kernels"),
-            "pipeline_tflops": round(GFLOP_PER_FRAME * fps / 1e3, 3),
-            "pipeline_frac": round(GFLOP_PER_FRAME * fps / 1e3 / peak, 4),
         }
-        # Both passes run the wide stride-1 3x3 convolutions (RPN, 256-channel stage; float32 also the
-        # 128-channel stage) in Winograd F(4x4, 3x3) form (1/4 of the multiplies).  Kernel rows and `achieved` count the FLOPs a kernel
-        # EXECUTES; pipeline_tflops counts the layer definitions' FLOPs (the direct form, the figure the
-        # metric's 354.5 GFLOP per frame stands for).  The executed total is reported next to it.
+        # The wide stride-1 3x3 convolutions (RPN, 256-channel stage; float32 also the 128-channel stage) run in
+        # Winograd F(4x4, 3x3) form (1/4 of the multiplies).  Kernel rows and `achieved` count the FLOPs a kernel
+        # EXECUTES, and so does the pass's utilisation (pipeline_executed_*); the graph definition's FLOPs (every
+        # layer direct: the metric's 354.5 GFLOP per 1080p frame) give an algorithmic rate reported beside it.
         executed = sum(r["flops"] for r in iso_rows) / args.frames / 1e9
         roof["executed_gflop_per_frame"] = round(executed, 2)
         roof["pipeline_executed_tflops"] = round(executed * fps / 1e3, 3)
         roof["pipeline_executed_frac"] = round(executed * fps / 1e3 / peak, 4)
-        roof["flop_note"] = ("pipeline_tflops = %.1f GFLOP per frame (every layer as a direct convolution) x frames/s; "
-                             "pipeline_executed_* = FLOPs the kernels executed (Winograd F(4x4,3x3) layers at 1/4 of "
-                             "the direct form's, GEMM row padding included)" % GFLOP_PER_FRAME)
+        roof["direct_equivalent_gflop_per_frame"] = GFLOP_PER_FRAME
+        roof["pipeline_direct_equivalent_tflops"] = round(GFLOP_PER_FRAME * fps / 1e3, 3)
+        roof["flop_note"] = ("pipeline_executed_* = FLOPs the kernels executed over the whole pass x frames/s against the "
+                             "matrix peak: the utilisation of the pass (Winograd F(4x4,3x3) layers count a quarter of their "
+                             "direct form, GEMM row padding included).  pipeline_direct_equivalent_tflops = %.1f GFLOP per "
+                             "frame (every layer as a direct convolution, the graph's definition) x frames/s: an algorithmic "
+                             "rate, NOT a utilisation -- part of those FLOPs were never executed" % GFLOP_PER_FRAME)
         iso = [r for r in iso_rows if r["kernel"] == dom["kernel"]][0]
         itf = iso["flops"] / (iso["ms"] * 1e-3) / 1e12
         roof["isolated"] = {
@@ -424,10 +637,7 @@ def main():
             "avg_launch_ms": round(iso["ms"] / iso["launches"], 4),
             "all_conv_tflops": round(sum(r["flops"] for r in conv) / (sum(r["ms"] for r in conv) * 1e-3) / 1e12, 3),
             "note": "same kernel in one extra untimed step on a single stream"}
-        table = [{"kernel": r["kernel"], "launches": r["launches"], "ms": round(r["ms"], 3),
-                  "tflops": round(r["flops"] / (r["ms"] * 1e-3) / 1e12, 3) if r["flops"] else None,
-                  "gbs": round(r["bytes"] / (r["ms"] * 1e-3) / 1e9, 1)} for r in sorted(iso_rows, key=lambda r: -r["ms"])]
-        return roof, table
+        return roof, _kernel_table(iso_rows)
 
     def measure_direct():
         """The float32 pass with every 3x3 layer in its direct form (FD_WINOGRAD=0; the form is chosen when a
@@ -468,87 +678,100 @@ def main():
     seen = torch.tensor([1], dtype=torch.int64, device=device)
     if distributed:
         dist.all_reduce(seen)
-
-    if rank == 0:
-        total_frames = args.frames * args.steps * world
-        fps = total_frames / head["elapsed"]
-        split_head = args.precision == "f16x3"
-        line = {
-            "metric": "1080p frames/sec (node)",
-            "value": round(fps, 3),
-            "unit": "frames/s",
-            "n_gpus": world,
-            "n_ranks_seen": int(seen.item()),
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": round(1000.0 * head["elapsed"] / args.steps, 3),
-            "higher_is_better": True,
-            "scaling": "weak",
-            "vs_baseline": None,
-            "dtype": ("f32 operands as fp16 hi+lo pairs (22 significant bits, fp16 range), 3 f16 MFMAs per product, f32 accumulate"
-                      if split_head else "f32"),
-            "data": "synthetic",
-            "config": {"workload": "batch of %d synthetic 1080p frames per GPU resident in HBM, full Faster R-CNN "
-                                   "(ResNet-50) cascade, micro-batches of %d on %d HIP stream(s)"
-                                   % (args.frames, B, args.streams),
-                       "frames_per_step_per_gpu": args.frames, "micro_batch": B, "streams": args.streams,
-                       "height": H, "width": W,
-                       "rpn_pre_nms_top_n": 1000, "rpn_post_nms_top_n": 10, "rpn_min_size": 50,
-                       "weights": "seeded random (synthetic:0)", "detections_in_last_step": n_boxes,
-                       "convolution_forms": (("the RPN's 3x3 layer and the stride-1 3x3 layers of the 256-channel stage run as "
-                                              "Winograd F(4x4,3x3) on fp16 hi+lo pairs (FD_WINOGRAD=%s), the rest direct"
-                                              if split_head else
-                                              "every layer a float32 convolution of the reference's graph; the stride-1 3x3 "
-                                              "layers with 128 or more channels and the RPN's 3x3 run as Winograd "
-                                              "F(4x4,3x3) in float32 (FD_WINOGRAD=%s), the rest direct; the measured error "
-                                              "against float64 is in accuracy_vs_float64")
-                                             % os.environ.get("FD_WINOGRAD", "4")),
-                       "frames_start": "pinned host memory (PCIe upload timed)" if args.from_host else "HBM",
-                       "library_build": _lib.lib().fd_build_id().decode("ascii")},
-        }
-        roof, table = roofline_of(head, fps)
-        if roof:
-            line["roofline"] = roof
-            line["kernels_single_stream_step"] = table
-        if not split_head and B == PMC_BATCH:
-            line["hbm_whole_pass"] = hbm_whole_pass(fps)
-        if head2:
-            line["two_streams"] = {"value": round(total_frames / head2["elapsed"], 3), "unit": "frames/s",
-                                   "ms_per_step": round(1000.0 * head2["elapsed"] / args.steps, 3), "streams": 2,
-                                   "dtype": line["dtype"]}
-        if direct_elapsed:
-            line["f32_direct_convolutions"] = {
-                "value": round(total_frames / direct_elapsed, 3), "unit": "frames/s",
-                "ms_per_step": round(1000.0 * direct_elapsed / args.steps, 3), "streams": 1, "dtype": "f32",
-                "pipeline_tflops": round(GFLOP_PER_FRAME * total_frames / direct_elapsed / 1e3, 3),
-                "pipeline_frac": round(GFLOP_PER_FRAME * total_frames / direct_elapsed / 1e3 / PEAK_FP32_MATRIX_TFLOPS, 4),
-                "note": "the headline pass with FD_WINOGRAD=0: every 3x3 layer as a direct float32 convolution "
-                        "(%.1f GFLOP executed per frame: pipeline_tflops are executed FLOPs here), for readers who want the "
-                        "headline without the Winograd form"
-                        % GFLOP_PER_FRAME}
-        acc = None
-        if do_split and args.check_frames > 0:
-            acc = accuracy_vs_float64(pipe, frames, min(args.check_frames, args.frames))
-            line["accuracy_vs_float64"] = acc["f32"]
-        if sub:
-            sfps = total_frames / sub["elapsed"]
-            sroof, stable = roofline_of(sub, sfps)
-            clamped_timed = int(sum(int(o[2][1].item()) for o in sub["outs"]))
-            rec = {"value": round(sfps, 3), "unit": "frames/s", "ms_per_step": round(1000.0 * sub["elapsed"] / args.steps, 3),
-                   "streams": args.split_streams,
-                   "dtype": "f32 operands as fp16 hi+lo pairs (22 significant bits, fp16 range), 3 f16 MFMAs per "
-                            "product, f32 accumulate",
-                   "roofline": sroof, "kernels_single_stream_step": stable,
-                   "clamped_values_last_timed_step": clamped_timed}
-            if acc:
-                rec.update(acc["f16x3"])
-            line["f16x3"] = rec
-        if not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline()
-        print(json.dumps(line), flush=True)
-    if distributed:
-        barrier()              # the other ranks wait here while rank 0 runs the untimed checks
+        n_seen = int(seen.item())
+        # Everything below is rank 0's alone (per-GPU sub-records, the float64 check, the CPU baseline: minutes of
+        # host work).  The process group ends here on every rank, so no rank sits in a collective with a watchdog
+        # running, and the other ranks leave the host's cores to the baseline.
+        barrier()
         dist.destroy_process_group()
+    else:
+        n_seen = int(seen.item())
+    if rank != 0:
+        pipe.close()
+        return
+
+    total_frames = args.frames * args.steps * world
+    fps = total_frames / head["elapsed"]
+    split_head = args.precision == "f16x3"
+    line = {
+        "metric": "1080p frames/sec (node)" if (H, W) == (1080, 1920) else "%dx%d frames/sec (node)" % (H, W),
+        "value": round(fps, 3),
+        "unit": "frames/s",
+        "n_gpus": world,
+        "n_ranks_seen": n_seen,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": round(1000.0 * head["elapsed"] / args.steps, 3),
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": ("f32 operands as fp16 hi+lo pairs (22 significant bits, fp16 range), 3 f16 MFMAs per product, f32 accumulate"
+                  if split_head else "f32"),
+        "data": "synthetic",
+        "config": {"workload": "batch of %d synthetic %s frames per GPU resident in HBM, full Faster R-CNN "
+                               "(ResNet-50) cascade, micro-batches of %d on %d HIP stream(s)"
+                               % (args.frames, "1080p" if (H, W) == (1080, 1920) else "%dx%d" % (H, W), B, args.streams),
+                   "frames_per_step_per_gpu": args.frames, "micro_batch": B, "streams": args.streams,
+                   "height": H, "width": W,
+                   "rpn_pre_nms_top_n": 1000, "rpn_post_nms_top_n": 10, "rpn_min_size": 50,
+                   "weights": "seeded random (synthetic:0)", "detections_in_last_step": n_boxes,
+                   "convolution_forms": (("the RPN's 3x3 layer and the stride-1 3x3 layers of the 256-channel stage run as "
+                                          "Winograd F(4x4,3x3) on fp16 hi+lo pairs (FD_WINOGRAD=%s), the rest direct"
+                                          if split_head else
+                                          "every layer a float32 convolution of the reference's graph; the stride-1 3x3 "
+                                          "layers with 128 or more channels and the RPN's 3x3 run as Winograd "
+                                          "F(4x4,3x3) in float32 (FD_WINOGRAD=%s), the rest direct; the measured error "
+                                          "against float64 is in accuracy_vs_float64")
+                                         % os.environ.get("FD_WINOGRAD", "4")),
+                   "frames_start": "pinned host memory (PCIe upload timed)" if args.from_host else "HBM",
+                   "library_build": _lib.lib().fd_build_id().decode("ascii")},
+    }
+    roof, table = roofline_of(head, fps)
+    if roof:
+        line["roofline"] = roof
+        line["hbm_bound_stages"] = hbm_bound_stages(table)
+        line["kernels_single_stream_step"] = table
+    if not split_head and B == PMC_BATCH and (H, W) == (1080, 1920):
+        line["hbm_whole_pass"] = hbm_whole_pass(fps)
+    if head2:
+        line["two_streams"] = {"value": round(total_frames / head2["elapsed"], 3), "unit": "frames/s",
+                               "ms_per_step": round(1000.0 * head2["elapsed"] / args.steps, 3), "streams": 2,
+                               "dtype": line["dtype"]}
+    if direct_elapsed:
+        line["f32_direct_convolutions"] = {
+            "value": round(total_frames / direct_elapsed, 3), "unit": "frames/s",
+            "ms_per_step": round(1000.0 * direct_elapsed / args.steps, 3), "streams": 1, "dtype": "f32",
+            "pipeline_executed_tflops": round(GFLOP_PER_FRAME * total_frames / direct_elapsed / 1e3, 3),
+            "pipeline_executed_frac": round(GFLOP_PER_FRAME * total_frames / direct_elapsed / 1e3 / PEAK_FP32_MATRIX_TFLOPS, 4),
+            "note": "the headline pass with FD_WINOGRAD=0: every 3x3 layer as a direct float32 convolution "
+                    "(%.1f GFLOP executed per frame), for readers who want the headline without the Winograd form"
+                    % GFLOP_PER_FRAME}
+    acc = None
+    if args.check_frames > 0 and not split_head:
+        acc = accuracy_vs_float64(pipe, frames, min(args.check_frames, args.frames),
+                                  ("f32", "f16x3") if do_split else ("f32",))
+        line["accuracy_vs_float64"] = acc["f32"]
+    if sub:
+        sfps = total_frames / sub["elapsed"]
+        sroof, stable = roofline_of(sub, sfps)
+        clamped_timed = int(sum(int(o[2][1].item()) for o in sub["outs"]))
+        rec = {"value": round(sfps, 3), "unit": "frames/s", "ms_per_step": round(1000.0 * sub["elapsed"] / args.steps, 3),
+               "streams": args.split_streams,
+               "dtype": "f32 operands as fp16 hi+lo pairs (22 significant bits, fp16 range), 3 f16 MFMAs per "
+                        "product, f32 accumulate",
+               "roofline": sroof, "kernels_single_stream_step": stable,
+               "clamped_values_last_timed_step": clamped_timed}
+        if acc:
+            rec.update(acc["f16x3"])
+        line["f16x3"] = rec
+    if not args.no_config_records and not split_head and (H, W) == (1080, 1920):
+        pipe.set_precision(args.precision)
+        line["configs"] = config_records(pipe.detectors[0], frames, device)
+    pipe.close()
+    del frames
+    if not args.no_cpu_baseline:
+        line["cpu_baseline"] = cpu_baseline()
+    print(json.dumps(line), flush=True)
 
 
 if __name__ == "__main__":

@@ -1,5 +1,7 @@
 """bench.py prints exactly one JSON line with the fields the benchmark contract names: a float32
-headline, the f16x3 sub-record with its measured error, roofline and cpu_baseline."""
+headline with roofline and cpu_baseline, the sub-records of the other configurations (single-frame latency,
+4K frames, dense crowd, front-end resize) with the HBM fractions of the memory-bound stages, and on request
+the f16x3 sub-record with its measured error."""
 import json
 import os
 import subprocess
@@ -26,7 +28,7 @@ def _check_roofline(r):
 
 def test_bench_prints_one_json_line_with_the_contract_fields():
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--frames", "16", "--steps", "1", "--warmup", "1",
-                          "--check-frames", "1", "--direct-record"], cwd=ROOT, capture_output=True, text=True, timeout=900)
+                          "--check-frames", "1", "--direct-record", "--split-record"], cwd=ROOT, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.strip()]
     assert len(lines) == 1, out.stdout[-2000:]
@@ -44,7 +46,22 @@ def test_bench_prints_one_json_line_with_the_contract_fields():
     assert d["roofline"]["peak"] == 157.3 and d["roofline"]["kernel"].startswith("conv_f32")
     # definition FLOPs (every layer as a direct convolution) and the FLOPs the kernels executed
     assert 0 < d["roofline"]["executed_gflop_per_frame"] <= 354.5 * 1.02
-    assert d["roofline"]["pipeline_executed_frac"] <= d["roofline"]["pipeline_frac"] * 1.02
+    assert 0 < d["roofline"]["pipeline_executed_frac"] < 1
+    assert d["roofline"]["pipeline_executed_tflops"] <= d["roofline"]["pipeline_direct_equivalent_tflops"] * 1.02
+    # the memory-bound stages carry their fraction of the HBM peak
+    for name in ("proposal_decode", "roipool", "nms_mask+nms_reduce"):
+        r = d["hbm_bound_stages"][name]
+        assert r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3, name
+    # the other configurations of the benchmark definition, same precision, same process
+    c = d["configs"]
+    assert 0 < c["latency_1080p"]["ms_back_to_back"] <= c["latency_1080p"]["ms"] * 1.05 and c["latency_1080p"]["ms"] < 20
+    assert c["frame_4k"]["value"] > 0 and c["frame_4k"]["ms_single_frame"] > c["latency_1080p"]["ms_back_to_back"]
+    dc = c["dense_crowd"]
+    assert dc["rois_into_stage4"] == 6000 and dc["candidates_into_rpn_nms"] >= 90000 and dc["ms"] > 0
+    assert "nms_mask+nms_reduce" in dc["hbm_bound_stages"]
+    rz = c["frontend_resize"]
+    assert rz["bound"] == "hbm" and rz["algorithmic_bytes"] == 16 * 3 * (1080 * 1920 + 562 * 1000)
+    assert abs(rz["frac"] - rz["achieved"] / rz["peak"]) < 1e-3 and 0 < rz["frac"] < 1
     # traffic of the whole float32 pass against the HBM peak: a measurement on this kernel set, or null with the reason
     h = d["hbm_whole_pass"]
     assert h["note"] and (h["bytes_per_frame"] is None or
@@ -90,7 +107,7 @@ def test_one_rank_under_the_distributed_launcher_over_rccl():
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
                           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
                           "--gpus", "1", "--frames", "16", "--steps", "1", "--warmup", "1", "--check-frames", "0",
-                          "--no-split-record", "--no-cpu-baseline"], cwd=ROOT, capture_output=True, text=True, timeout=600,
+                          "--no-config-records", "--no-cpu-baseline"], cwd=ROOT, capture_output=True, text=True, timeout=600,
                          env=env)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.strip().startswith("{")]
