@@ -437,7 +437,7 @@ def main():
     ap.add_argument("--two-streams", action="store_true",
                     help="also time the headline precision on two streams (sub-record two_streams; off by default so "
                          "that a kernel trace of the default run holds single-stream launches of the headline kernels only)")
-    ap.add_argument("--precision", default="f32", choices=["f32", "f16x3"],
+    ap.add_argument("--precision", default="f32", choices=["f32", "f16x3", "bf16x3"],
                     help="arithmetic of the HEADLINE: float32 operands (the reference's, default), or the f16x3 split")
     ap.add_argument("--height", type=int, default=1080, help="frame height of the headline workload")
     ap.add_argument("--width", type=int, default=1920, help="frame width of the headline workload")
@@ -603,13 +603,15 @@ def main():
         # split precision executes 3 f16 MFMA FLOPs per algorithmic FLOP, so the ceiling for
         # ALGORITHMIC FLOP/s on that path is the dense f16 MFMA peak / 3
         split = dom["kernel"].startswith("conv_split")
-        peak = PEAK_F16_MATRIX_TFLOPS / 3.0 if split else PEAK_FP32_MATRIX_TFLOPS
+        b3 = "_b3" in dom["kernel"]
+        peak = PEAK_F16_MATRIX_TFLOPS / 3.0 if split else PEAK_F16_MATRIX_TFLOPS / 6.0 if b3 else PEAK_FP32_MATRIX_TFLOPS
         traffic, note = pmc_traffic(dom["kernel"]) if B == PMC_BATCH else (None, "PMC passes are taken at micro-batch %d" % PMC_BATCH)
         roof = {
             "bound": "mfma", "kernel": dom["kernel"], "achieved": round(tf, 3), "peak": round(peak, 1),
             "unit": "TFLOP/s", "frac": round(tf / peak, 4), "traffic": traffic,
             "traffic_note": note + ("; algorithmic bytes per launch %.0f" % (dom["bytes"] / dom["launches"])),
-            "peak_note": ("dense f16 MFMA peak 2500 TFLOP/s / 3 MFMAs per product" if split else "dense fp32 MFMA peak"),
+            "peak_note": ("dense f16 MFMA peak 2500 TFLOP/s / 3 MFMAs per product" if split else
+                          "dense bf16 MFMA peak 2500 TFLOP/s / 6 MFMAs per product" if b3 else "dense fp32 MFMA peak"),
             "launches": dom["launches"], "avg_launch_ms": round(dom["ms"] / dom["launches"], 4),
             "flop_per_launch": round(dom["flops"] / dom["launches"]),
             "measured": "HIP events around every launch of this kernel inside the timed region (%d stream%s)"
@@ -749,8 +751,8 @@ def main():
     acc = None
     if args.check_frames > 0 and not split_head:
         acc = accuracy_vs_float64(pipe, frames, min(args.check_frames, args.frames),
-                                  ("f32", "f16x3") if do_split else ("f32",))
-        line["accuracy_vs_float64"] = acc["f32"]
+                                  (args.precision, "f16x3") if do_split else (args.precision,))
+        line["accuracy_vs_float64"] = acc[args.precision]
     if sub:
         sfps = total_frames / sub["elapsed"]
         sroof, stable = roofline_of(sub, sfps)

@@ -82,6 +82,8 @@ SIGNATURES = {
                                    vp]),
     "fd_conv2d": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                             vp, vp, vp, C.c_int, vp, vp, vp]),
+    "fd_conv2d_bf16x3": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_int,
+                                   C.c_int, vp, vp, vp, C.c_int, vp, vp, vp]),
     "fd_conv2d_f16x3": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_int,
                                   C.c_int, vp, vp, vp, C.c_int, vp, vp, vp]),
     "fd_conv2d_winograd": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int, vp, C.c_int, C.c_int, vp, vp]),

@@ -469,9 +469,30 @@ int fc_head(const float* flat, int n, int c, const float* w_cls, const float* b_
 // =================================================================================
 extern "C" {
 
+static int conv2d_f32_operands(fd_ctx* ctx, const float* x_nhwc, int batch, int height, int width, int cin, const float* w_oihw,
+                               int cout, int kh, int kw, int stride, int pad, const float* bias, const float* pre_scale,
+                               const float* pre_shift, int relu, const float* residual, float* y_nhwc, void* stream,
+                               bool b3);
+
 int fd_conv2d(fd_ctx* ctx, const float* x_nhwc, int batch, int height, int width, int cin, const float* w_oihw,
               int cout, int kh, int kw, int stride, int pad, const float* bias, const float* pre_scale,
               const float* pre_shift, int relu, const float* residual, float* y_nhwc, void* stream) {
+    return conv2d_f32_operands(ctx, x_nhwc, batch, height, width, cin, w_oihw, cout, kh, kw, stride, pad, bias, pre_scale,
+                               pre_shift, relu, residual, y_nhwc, stream, false);
+}
+
+int fd_conv2d_bf16x3(fd_ctx* ctx, const float* x_nhwc, int batch, int height, int width, int cin, const float* w_oihw,
+                     int cout, int kh, int kw, int stride, int pad, const float* bias, const float* pre_scale,
+                     const float* pre_shift, int relu, const float* residual, float* y_nhwc, void* stream) {
+    FD_REQUIRE(cout > 0 && cout % 8 == 0, "fd_conv2d_bf16x3: cout must be a multiple of 8 (got %d)", cout);
+    return conv2d_f32_operands(ctx, x_nhwc, batch, height, width, cin, w_oihw, cout, kh, kw, stride, pad, bias, pre_scale,
+                               pre_shift, relu, residual, y_nhwc, stream, true);
+}
+
+static int conv2d_f32_operands(fd_ctx* ctx, const float* x_nhwc, int batch, int height, int width, int cin, const float* w_oihw,
+                               int cout, int kh, int kw, int stride, int pad, const float* bias, const float* pre_scale,
+                               const float* pre_shift, int relu, const float* residual, float* y_nhwc, void* stream,
+                               bool b3) {
     FD_REQUIRE(ctx && x_nhwc && w_oihw && y_nhwc, "fd_conv2d: NULL argument");
     FD_REQUIRE(cin % 32 == 0 && cin > 0 && cout > 0, "fd_conv2d: cin must be a positive multiple of 32 (got %d)", cin);
     fd::ConvParams p;
@@ -484,11 +505,17 @@ int fd_conv2d(fd_ctx* ctx, const float* x_nhwc, int batch, int height, int width
     // (FD_F32_GLDS=0 keeps the register-staged kernel for comparisons).
     static const bool glds = !(getenv("FD_F32_GLDS") && atoi(getenv("FD_F32_GLDS")) == 0);
     const size_t x_bytes = (size_t)batch * height * width * cin * 4;
-    if (glds && !pre_scale && x_bytes < (1ull << 31) && p.s.packed_floats() * 4 < (1ull << 31) && cout % 8 == 0) {
+    const bool reach = x_bytes < (1ull << 31) && p.s.packed_floats() * 4 < (1ull << 31) && cout % 8 == 0;
+    FD_REQUIRE(!b3 || reach, "fd_conv2d_bf16x3: tensor beyond the 2^31-byte reach of the buffer-addressed kernels");
+    if ((glds || b3) && reach && (!pre_scale || b3)) {
         fd::SplitConvParams sp;
         sp.s = p.s; sp.w = packed; sp.w_inv_scale = 1.f; sp.bias = bias; sp.relu = relu; sp.f32 = true;
         fd::SplitConvOut o;
         o.y32 = y_nhwc;
+        o.b3 = b3;
+        if (pre_scale)     // BatchNorm + ReLU on load: the register-staged kernel
+            return fd::split_conv_forward_f32(sp, x_nhwc, pre_scale, pre_shift, batch, height, width, residual, o,
+                                              fd::as_stream(stream));
         return fd::split_conv_forward(sp, x_nhwc, batch, height, width, residual, o, fd::as_stream(stream));
     }
     return fd::conv_forward(p, x_nhwc, batch, height, width, residual, y_nhwc, fd::as_stream(stream));

@@ -31,9 +31,12 @@ namespace fd {
 // workgroup), so a chunk's weights are fetched after the previous chunk's epilogue instead of during it, and
 // only one set of residual registers is live (<= 168 registers); what a workgroup no longer overlaps inside
 // itself, the third workgroup covers.
-template <int BM, int MID, bool F32>
-__global__ __launch_bounds__(256, F32 ? 3 : 2) void conv_tail_fused_kernel(SplitKArgs a, SplitKArgs c, unsigned x_bytes,
+// B3 (with F32): products on the bf16 matrix cores (bf16x3_mma_step), both loops sign-balanced as in the
+// direct-to-LDS kernel.
+template <int BM, int MID, bool F32, bool B3 = false>
+__global__ __launch_bounds__(256, F32 && !B3 ? 3 : 2) void conv_tail_fused_kernel(SplitKArgs a, SplitKArgs c, unsigned x_bytes,
                                                                 unsigned w_bytes, unsigned w3_bytes) {
+    static_assert(!B3 || F32, "bf16x3 products are formed from float32 operand images");
 #if defined(__HIP_DEVICE_COMPILE__)
     static_assert(BM == 128 && MID == 64, "written for 128-pixel tiles of a 64-channel middle layer");
     constexpr int BN = MID;
@@ -138,10 +141,19 @@ __global__ __launch_bounds__(256, F32 ? 3 : 2) void conv_tail_fused_kernel(Split
         a_off[part] = (wm * (BM / 2) + frow) * 128 + pos;
         b_off[part] = (BM + wn * (BN / 2) + frow) * 128 + pos;
     }
+    const int half = (B3 && a.b3_balance > 0) ? max(1, min(nk - 1, (nk * a.b3_balance + 50) / 100)) : nk + 1;
+    unsigned flip = 0u;
 #define FD_STEP(CUR, KT)                                                                          \
     do {                                                                                          \
         if ((KT) + 1 < nk) FD_ISSUE((KT) + 1, (CUR) ^ 1);                                         \
-        if (F32) f32_mma_step<BM, BN>(sbase + (CUR) * STAGE * 4, a_off, b_off, acc);              \
+        if (B3) {                                                                                 \
+            if ((KT) == half) {                                                                   \
+                _Pragma("unroll") for (int mi = 0; mi < T::AM; ++mi)                              \
+                    _Pragma("unroll") for (int ni = 0; ni < T::AN; ++ni) acc[mi][ni] = -acc[mi][ni]; \
+                flip = 0x80000000u;                                                               \
+            }                                                                                     \
+            bf16x3_mma_step<BM, BN>(sbase + (CUR) * STAGE * 4, a_off, b_off, acc, flip);          \
+        } else if (F32) f32_mma_step<BM, BN>(sbase + (CUR) * STAGE * 4, a_off, b_off, acc);       \
         else split_mma_step<BM, BN>(sbase + (CUR) * STAGE * 4, a_off, b_off, acc);                \
         wait_vmcnt<0>();                                                                          \
         __syncthreads();                                                                          \
@@ -153,6 +165,12 @@ __global__ __launch_bounds__(256, F32 ? 3 : 2) void conv_tail_fused_kernel(Split
     for (int kt = 0; kt < nk; kt += 2) {
         FD_STEP(0, kt);
         if (kt + 1 < nk) FD_STEP(1, kt + 1);
+    }
+    if (B3 && flip) {
+#pragma unroll
+        for (int mi = 0; mi < T::AM; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < T::AN; ++ni) acc[mi][ni] = -acc[mi][ni];
     }
 #undef FD_STEP
 #undef FD_ISSUE
@@ -240,7 +258,7 @@ __global__ __launch_bounds__(256, F32 ? 3 : 2) void conv_tail_fused_kernel(Split
         _Pragma("unroll") for (int mi = 0; mi < T::AM; ++mi)                                      \
             _Pragma("unroll") for (int ni = 0; ni < T::AN; ++ni) acc3[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f}; \
         _Pragma("unroll") for (int kk = 0; kk < MID / 32; ++kk) {                                 \
-            if (F32) f32_mma_step<BM, BN>(sbase, a3_off[kk], b3_off[kk], acc3);                   \
+            if (F32) FD_MMA3(kk);                                                                 \
             else split_mma_step<BM, BN>(sbase, a3_off[kk], b3_off[kk], acc3);                     \
         }                                                                                         \
         __syncthreads();               /* every wave is done reading the weight chunk */          \
@@ -250,6 +268,25 @@ __global__ __launch_bounds__(256, F32 ? 3 : 2) void conv_tail_fused_kernel(Split
             __builtin_amdgcn_sched_barrier(0);                                                    \
         }                                                                                         \
         split_epilogue16<BM, BN, true>(c, smem, tile_m, (CH), wave, lane, acc3, RCUR);            \
+    } while (0)
+
+    // K-step kk of the 1x1 (two in all); bf16x3: the second one accumulated negated
+#define FD_MMA3(KK)                                                                               \
+    do {                                                                                          \
+        if (B3) {                                                                                 \
+            const bool neg_ = c.b3_balance > 0 && (KK) == MID / 32 - 1 && MID / 32 > 1;           \
+            if (neg_) {                                                                           \
+                _Pragma("unroll") for (int mi = 0; mi < T::AM; ++mi)                              \
+                    _Pragma("unroll") for (int ni = 0; ni < T::AN; ++ni) acc3[mi][ni] = -acc3[mi][ni]; \
+            }                                                                                     \
+            bf16x3_mma_step<BM, BN>(sbase, a3_off[KK], b3_off[KK], acc3, neg_ ? 0x80000000u : 0u); \
+            if (neg_) {                                                                           \
+                _Pragma("unroll") for (int mi = 0; mi < T::AM; ++mi)                              \
+                    _Pragma("unroll") for (int ni = 0; ni < T::AN; ++ni) acc3[mi][ni] = -acc3[mi][ni]; \
+            }                                                                                     \
+        } else {                                                                                  \
+            f32_mma_step<BM, BN>(sbase, a3_off[KK], b3_off[KK], acc3);                            \
+        }                                                                                         \
     } while (0)
 
     const int nch = c.Cout / 64;
@@ -269,7 +306,7 @@ __global__ __launch_bounds__(256, F32 ? 3 : 2) void conv_tail_fused_kernel(Split
 #pragma unroll
                 for (int ni = 0; ni < T::AN; ++ni) acc3[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int kk = 0; kk < MID / 32; ++kk) f32_mma_step<BM, BN>(sbase, a3_off[kk], b3_off[kk], acc3);
+            for (int kk = 0; kk < MID / 32; ++kk) FD_MMA3(kk);
             // (the epilogue's own first barrier separates the last weight read from the staging writes)
             split_epilogue16<BM, BN, true>(c, smem, tile_m, ch, wave, lane, acc3, res);
         }
@@ -284,6 +321,7 @@ __global__ __launch_bounds__(256, F32 ? 3 : 2) void conv_tail_fused_kernel(Split
         }
     }
 #undef FD_CHUNK
+#undef FD_MMA3
 #undef FD_WEIGHTS
 #endif
 }
@@ -315,10 +353,14 @@ int conv_tail_fused_forward(const SplitConvParams& p2, const SplitConvParams& p3
     c.w_inv_scale = p3.w_inv_scale; c.Cin = 64; c.Cout = s3.cout; c.KW = 1; c.pad = 0; c.K = 64; c.relu = p3.relu;
     c.tiles_n = s3.cout / 64;
     const int tiles_m = ceil_div(a.M, 128);
-    ProfScope scope(stream, f32 ? "conv_tail_fused_f32" : "conv_tail_fused", 2.0 * a.M * 64.0 * (double)a.K + 2.0 * a.M * (double)s3.cout * 64.0,
+    a.b3_balance = c.b3_balance = out.b3_balance;
+    ProfScope scope(stream, f32 ? (out.b3 ? "conv_tail_fused_b3" : "conv_tail_fused_f32") : "conv_tail_fused", 2.0 * a.M * 64.0 * (double)a.K + 2.0 * a.M * (double)s3.cout * 64.0,
                     4.0 * 64.0 * a.M + 4.0 * 64.0 * (a.K + s3.cout) +
                         4.0 * a.M * s3.cout * ((c.res ? 1.0 : 0.0) + (c.y32 ? 1.0 : 0.0) + (c.ysplit ? 1.0 : 0.0)));
-    if (f32)
+    if (f32 && out.b3)
+        hipLaunchKernelGGL((conv_tail_fused_kernel<128, 64, true, true>), dim3(tiles_m), dim3(256), 0, stream, a, c,
+                           (unsigned)x_bytes, (unsigned)w_bytes, (unsigned)w3_bytes);
+    else if (f32)
         hipLaunchKernelGGL((conv_tail_fused_kernel<128, 64, true>), dim3(tiles_m), dim3(256), 0, stream, a, c,
                            (unsigned)x_bytes, (unsigned)w_bytes, (unsigned)w3_bytes);
     else

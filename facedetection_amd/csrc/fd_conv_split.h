@@ -24,6 +24,10 @@ struct SplitConvOut {
     float* splitk_ws = nullptr;        // optional workspace for split-K partial sums (small grids only)
     size_t splitk_ws_floats = 0;
     unsigned* clamped = nullptr;       // device counter of values that left the fp16 range while being split, or NULL
+    bool b3 = false;                   // float32 operands only: products on the bf16 matrix cores (three-way bf16 split of
+                                       // both operands in registers, six partial products per multiply)
+    int b3_balance = 63;               // ... with this percentage of a tile's K-steps accumulated as +(sum), the rest as
+                                       // -(sum) (cancels the rounding bias of the bf16 matrix unit; 0: off)
 };
 
 int pack_conv_weights_split(const float* w_oihw, int cin_w, const ConvShape& s, const float* out_scale, float wscale,
@@ -105,8 +109,9 @@ long long wino_patches_padded(int batch, int h, int w, int tile, int align = 128
 bool wino_fits(const WinoConvParams& p, int batch, int h, int w);
 // x [B][H][W][cin] float32 -> y [B][H][W][cout] float32 (+ bias, ReLU).  Workspaces: v_ws holds
 // (tile + 2)^2 * wino_patches_padded * cin floats, m_ws (tile + 2)^2 * wino_patches_padded * cout floats.
+// b3: the (tile + 2)^2 GEMMs with bf16x3 products (the transforms stay float32).
 int wino_conv_forward(const WinoConvParams& p, const float* x, int batch, int h, int w, float* v_ws, float* m_ws,
-                      float* y, hipStream_t stream);
+                      float* y, hipStream_t stream, bool b3 = false, int b3_balance = 63);
 // Split-precision form (tile 4 only): x and y are split tensors (fd_split.h), the Winograd-domain input V is a
 // split tensor too (same bytes as float32), the GEMMs run on the f16 matrix cores (three MFMAs per product) and
 // leave M in float32.  Patches are padded to whole 256-row GEMM tiles: wino_patches_padded(..., 256).
@@ -123,8 +128,9 @@ int gemm_split_batched(const void* a_split, const void* w_split, unsigned w_set_
                        int k, int cout, float* y, hipStream_t stream);
 // nb independent float32 GEMMs in one launch on the 128 x 128 direct-to-LDS kernel:
 // y[b] [rows_pad][cout] = a[b] [rows_pad][k] * w[b]^T, w[b] = [cout_pad][k]; rows_pad % 128 == 0, k % 32 == 0.
+// b3: products on the bf16 matrix cores (three-way bf16 split of both operands), b3_balance as in SplitConvOut.
 int gemm_f32_batched(const float* a, const float* w, int nb, int rows_pad, int k, int cout, int cout_pad, float* y,
-                     hipStream_t stream);
+                     hipStream_t stream, bool b3 = false, int b3_balance = 63);
 
 int maxpool_3x3s2_split(const float* x, int batch, int h, int w, int c, const float* scale, const float* shift,
                         float* y32, void* ysplit, unsigned* clamped, hipStream_t stream, bool f32 = false);

@@ -297,9 +297,15 @@ __global__ __launch_bounds__(256, 2) void conv_split_kernel(SplitKArgs a) {
 // takes 976 us with the MFMAs removed and 1141 us with the LDS-DMA removed, 1476 us as it is).
 // F32: the operands are float32 (a staged row = 32 floats) and the products run on the fp32 matrix
 // cores; loads, LDS image, pipeline and epilogue are the same code.
-template <int BM, int BN, int NS, int WAVES = 4, bool F32 = false, int OCC = 0>
+// B3 (with F32): the same float32 operand images, products on the bf16 matrix cores (bf16x3_mma_step).  The bf16
+// matrix unit rounds its sums downwards (measured: the mean error of a K = 4608 layer is -2e-7 of the output rms,
+// against 3e-10 for the float32 unit, at equal rms error), a bias that survives averaging layers.  The second half of
+// a tile's K-steps is therefore accumulated as -(sum): the accumulators change sign at the midpoint and at the end and
+// the activation operand enters negated in between, so the two halves' biases cancel.
+template <int BM, int BN, int NS, int WAVES = 4, bool F32 = false, int OCC = 0, bool B3 = false>
 __global__ __launch_bounds__(WAVES * 64, OCC ? OCC : (WAVES == 4 ? 2 : 1)) void conv_split_glds_kernel(SplitKArgs a, unsigned x_bytes,
                                                                                       unsigned w_bytes) {
+    static_assert(!B3 || F32, "bf16x3 products are formed from float32 operand images");
 #if defined(__HIP_DEVICE_COMPILE__)   // buffer-resource builtins exist in device code only; the host pass needs just the stub
     constexpr int WROWS = BM / (WAVES / 2);     // rows of the tile per wave row
     using T = SplitTile<2 * WROWS, BN>;         // per-wave geometry: that of a 2 x 2 grid over 2 WROWS rows
@@ -446,10 +452,21 @@ __global__ __launch_bounds__(WAVES * 64, OCC ? OCC : (WAVES == 4 ? 2 : 1)) void 
         b_off[part] = (BM + wn * (BN / 2) + frow) * 128 + pos;
     }
 
+    // bf16x3: K-steps from `half` on are accumulated negated
+    const int half = (B3 && a.b3_balance > 0 && nk > 1) ? max(1, min(nk - 1, (nk * a.b3_balance + 50) / 100)) : nk + 1;
+    unsigned flip = 0u;
+#define FD_NEGATE()                                                                               \
+    do {                                                                                          \
+        _Pragma("unroll") for (int mi = 0; mi < T::AM; ++mi)                                      \
+            _Pragma("unroll") for (int ni = 0; ni < T::AN; ++ni) acc[mi][ni] = -acc[mi][ni];      \
+    } while (0)
 #define FD_STEP(CUR, KT)                                                                          \
     do {                                                                                          \
         if ((KT) + NS - 1 < nk) FD_ISSUE((KT) + NS - 1, ((CUR) + NS - 1) % NS);                   \
-        if (F32) f32_mma_step<2 * WROWS, BN>(sbase + (CUR) * STAGE * 4, a_off, b_off, acc);       \
+        if (B3) {                                                                                 \
+            if ((KT) == half) { FD_NEGATE(); flip = 0x80000000u; }                                \
+            bf16x3_mma_step<2 * WROWS, BN>(sbase + (CUR) * STAGE * 4, a_off, b_off, acc, flip);   \
+        } else if (F32) f32_mma_step<2 * WROWS, BN>(sbase + (CUR) * STAGE * 4, a_off, b_off, acc); \
         else split_mma_step<2 * WROWS, BN>(sbase + (CUR) * STAGE * 4, a_off, b_off, acc);         \
         FD_WAIT(min(NS - 2, nk - 2 - (KT)));                                                      \
         pipeline_barrier();                                                                       \
@@ -471,7 +488,9 @@ __global__ __launch_bounds__(WAVES * 64, OCC ? OCC : (WAVES == 4 ? 2 : 1)) void 
             if (kt + 3 < nk) FD_STEP(3, kt + 3);
         }
     }
+    if (B3 && flip) FD_NEGATE();
 #undef FD_STEP
+#undef FD_NEGATE
 #undef FD_WAIT
 #undef FD_ISSUE
 #undef FD_TAP
@@ -486,9 +505,13 @@ __global__ __launch_bounds__(WAVES * 64, OCC ? OCC : (WAVES == 4 ? 2 : 1)) void 
 #endif
 }
 
-template <int BM, int BN, int NS, int WAVES = 4, bool F32 = false, int OCC = 0>
+template <int BM, int BN, int NS, int WAVES = 4, bool F32 = false, int OCC = 0, bool B3 = false>
 static int launch_split_glds(const SplitKArgs& a, size_t x_bytes, size_t w_bytes, hipStream_t stream) {
-    static const std::string name = std::string(F32 ? "conv_f32_" : "conv_split_") + std::to_string(BM) + "x" + std::to_string(BN) +
+    if constexpr (F32 && !B3) {
+        // bf16x3: same tensors, tiles and pipeline, products on the bf16 matrix cores
+        if (a.f32 == 2) return launch_split_glds<BM, BN, NS, WAVES, true, OCC, true>(a, x_bytes, w_bytes, stream);
+    }
+    static const std::string name = std::string(B3 ? "conv_b3_" : F32 ? "conv_f32_" : "conv_split_") + std::to_string(BM) + "x" + std::to_string(BN) +
                                     (OCC ? "_o" + std::to_string(OCC) : std::string());
     ProfScope scope(stream, name.c_str(), 2.0 * a.M * a.Cout * (double)a.K,
                     (double)a.H * a.W * (a.M / ((double)a.Ho * a.Wo)) * 4.0 * a.Cin + 4.0 * a.Cout * (double)a.K +
@@ -496,7 +519,7 @@ static int launch_split_glds(const SplitKArgs& a, size_t x_bytes, size_t w_bytes
     SplitKArgs k = a;
     const int tiles_m = ceil_div(a.M, BM);
     k.tiles_n = ceil_div(a.Cout, BN);
-    hipLaunchKernelGGL((conv_split_glds_kernel<BM, BN, NS, WAVES, F32, OCC>), dim3(tiles_m * k.tiles_n * k.ksplit),
+    hipLaunchKernelGGL((conv_split_glds_kernel<BM, BN, NS, WAVES, F32, OCC, B3>), dim3(tiles_m * k.tiles_n * k.ksplit),
                        dim3(WAVES * 64), 0, stream, k, (unsigned)x_bytes, (unsigned)w_bytes);
     FD_LAUNCH_CHECK();
     return FD_OK;
@@ -517,8 +540,9 @@ enum { REG_PRE = 0, REG_STEM = 1 };
 
 // F32 (REG_PRE only): float32 operands -- the activated values go to LDS as floats (one 16-byte chunk
 // per thread) and the products run on the fp32 matrix cores.
-template <int BM, int BN, int MODE, bool F32 = false>
+template <int BM, int BN, int MODE, bool F32 = false, bool B3 = false>
 __global__ __launch_bounds__(256, 2) void conv_split_reg_kernel(SplitKArgs a, unsigned x_bytes, unsigned w_bytes) {
+    static_assert(!B3 || F32, "bf16x3 products are formed from float32 operand images");
 #if defined(__HIP_DEVICE_COMPILE__)
     using T = SplitTile<BM, BN>;
     constexpr int RA = BM / 32;                  // activation rows per thread and K-step
@@ -679,11 +703,22 @@ __global__ __launch_bounds__(256, 2) void conv_split_reg_kernel(SplitKArgs a, un
     }
     unsigned lok = 0;     // validity bits that belong to the registers in flight
 
+    // bf16x3: K-steps from `half` on are accumulated negated (see conv_split_glds_kernel)
+    const int half = (B3 && a.b3_balance > 0 && nk > 1) ? max(1, min(nk - 1, (nk * a.b3_balance + 50) / 100)) : nk + 1;
+    unsigned flip = 0u;
+#define FD_NEGATE()                                                                               \
+    do {                                                                                          \
+        _Pragma("unroll") for (int mi = 0; mi < T::AM; ++mi)                                      \
+            _Pragma("unroll") for (int ni = 0; ni < T::AN; ++ni) acc[mi][ni] = -acc[mi][ni];      \
+    } while (0)
 #define FD_STEP(CUR, KT)                                                                          \
     do {                                                                                          \
         const bool more_ = (KT) + 1 < nk;                                                         \
         if (more_) FD_GLOAD((KT) + 1, (CUR) ^ 1);                                                 \
-        if (F32) f32_mma_step<BM, BN>(sbase + (CUR) * STAGE * 4, a_off, b_off, acc);              \
+        if (B3) {                                                                                 \
+            if ((KT) == half) { FD_NEGATE(); flip = 0x80000000u; }                                \
+            bf16x3_mma_step<BM, BN>(sbase + (CUR) * STAGE * 4, a_off, b_off, acc, flip);          \
+        } else if (F32) f32_mma_step<BM, BN>(sbase + (CUR) * STAGE * 4, a_off, b_off, acc);       \
         else split_mma_step<BM, BN>(sbase + (CUR) * STAGE * 4, a_off, b_off, acc);                \
         if (more_) FD_LSTORE((CUR) ^ 1);                                                          \
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                          \
@@ -699,7 +734,9 @@ __global__ __launch_bounds__(256, 2) void conv_split_reg_kernel(SplitKArgs a, un
         FD_STEP(0, kt);
         if (kt + 1 < nk) FD_STEP(1, kt + 1);
     }
+    if (B3 && flip) FD_NEGATE();
 #undef FD_STEP
+#undef FD_NEGATE
 #undef FD_LSTORE
 #undef FD_GLOAD
 #undef FD_TAP
@@ -715,10 +752,13 @@ __global__ __launch_bounds__(256, 2) void conv_split_reg_kernel(SplitKArgs a, un
 #endif
 }
 
-template <int BM, int BN, int MODE, bool F32 = false>
+template <int BM, int BN, int MODE, bool F32 = false, bool B3 = false>
 static int launch_split_reg(const SplitKArgs& a, size_t x_bytes, size_t w_bytes, hipStream_t stream) {
     static_assert(!F32 || MODE == REG_PRE, "the float32 form exists for the BatchNorm-on-load kernel only");
-    static const std::string name = std::string(F32 ? "conv_f32_" : "conv_split_") + std::to_string(BM) + "x" +
+    if constexpr (F32 && !B3) {
+        if (a.f32 == 2) return launch_split_reg<BM, BN, MODE, true, true>(a, x_bytes, w_bytes, stream);
+    }
+    static const std::string name = std::string(B3 ? "conv_b3_" : F32 ? "conv_f32_" : "conv_split_") + std::to_string(BM) + "x" +
                                     std::to_string(BN) + (MODE == REG_STEM ? "_stem" : "_pre");
     const double taps = MODE == REG_STEM ? 147.0 : (double)a.K;
     const double cin_bytes = MODE == REG_STEM ? 16.0 : 4.0 * a.Cin;
@@ -728,7 +768,7 @@ static int launch_split_reg(const SplitKArgs& a, size_t x_bytes, size_t w_bytes,
     SplitKArgs k = a;
     const int tiles_m = ceil_div(a.M, BM);
     k.tiles_n = ceil_div(a.Cout, BN);
-    hipLaunchKernelGGL((conv_split_reg_kernel<BM, BN, MODE, F32>), dim3(tiles_m * k.tiles_n * k.ksplit), dim3(256), 0,
+    hipLaunchKernelGGL((conv_split_reg_kernel<BM, BN, MODE, F32, B3>), dim3(tiles_m * k.tiles_n * k.ksplit), dim3(256), 0,
                        stream, k, (unsigned)x_bytes, (unsigned)w_bytes);
     FD_LAUNCH_CHECK();
     return FD_OK;
@@ -856,6 +896,11 @@ static int split_conv_dispatch(const SplitConvParams& p, const void* x_split, co
     a.H = h; a.W = w; a.Cin = s.cin; a.Ho = ho; a.Wo = wo; a.Cout = s.cout; a.KW = s.kwp;
     a.stride = s.stride; a.pad = s.pad; a.K = s.k(); a.M = (int)m_ll; a.relu = p.relu; a.tiles_n = 0;
     a.ksplit = 1; a.kchunk = a.K / SBK; a.partial = nullptr; a.clamped = out.clamped; a.f32 = p.f32 ? 1 : 0;
+    // FD_BF16X3=1 / FD_B3_BALANCE=<percent>: overrides for probes of the operator entry points
+    static const int b3_env = getenv("FD_BF16X3") ? atoi(getenv("FD_BF16X3")) : 0;
+    static const int b3_bal = getenv("FD_B3_BALANCE") ? atoi(getenv("FD_B3_BALANCE")) : -1;
+    if (p.f32 && (out.b3 || b3_env)) a.f32 = 2;
+    a.b3_balance = b3_bal >= 0 ? b3_bal : out.b3_balance;
     FD_REQUIRE(!(stem && pre_scale), "split conv: the stem takes the staged image only");
     // the buffer-addressed kernels use 32-bit byte offsets below 2^31 into both tensors
     const size_t x_bytes = (size_t)batch * h * w * s.cin * 4, w_bytes = s.packed_floats() * 4;
@@ -884,6 +929,17 @@ static int split_conv_dispatch(const SplitConvParams& p, const void* x_split, co
             if (s.cout > 64 && t128 >= 384) return launch_split_reg<128, 128, REG_PRE, true>(a, x_bytes, w_bytes, stream);
             if (t12864 >= 384) return launch_split_reg<128, 64, REG_PRE, true>(a, x_bytes, w_bytes, stream);
             return launch_split_reg<64, 64, REG_PRE, true>(a, x_bytes, w_bytes, stream);
+        }
+        if (a.f32 == 2) {
+            // bf16x3 products: a K-step lasts 3/8 as long as with float32 products, so the two-stage four-wave tiles
+            // no longer keep a step's loads a memory round trip ahead; the eight-wave 256-row tiles (one workgroup per
+            // CU, as for f16x3) run longer steps and convert each operand value for twice as many multiplies
+            static const int b3_big = getenv("FD_B3_BIG") ? atoi(getenv("FD_B3_BIG")) : 1;
+            const long long t256 = (long long)ceil_div(a.M, 256) * ceil_div(s.cout, 128);
+            if (b3_big == 1 && s.cout >= 256 && a.K >= 128 && t256 >= 448)
+                return launch_split_glds<256, 256, 2, 8, true, 0, true>(a, x_bytes, w_bytes, stream);
+            if (b3_big && s.cout > 64 && a.K >= 128 && t256 >= 448)
+                return launch_split_glds<256, 128, 3, 8, true, 0, true>(a, x_bytes, w_bytes, stream);
         }
         // K = 256 layers (8 K-steps per tile): the per-tile prologue and epilogue weigh as much as the loop, and
         // three workgroups per CU on 128 x 64 tiles (two pipeline stages, 48 KB of LDS, 105 registers) cover
@@ -939,7 +995,7 @@ static int split_conv_dispatch(const SplitConvParams& p, const void* x_split, co
 }
 
 int gemm_f32_batched(const float* a_mat, const float* w, int nb, int rows_pad, int k, int cout, int cout_pad, float* y,
-                     hipStream_t stream) {
+                     hipStream_t stream, bool b3, int b3_balance) {
     FD_REQUIRE(a_mat && w && y && nb > 0 && rows_pad > 0 && rows_pad % 128 == 0 && k % 32 == 0 && cout % 8 == 0 &&
                    cout_pad % 128 == 0 && cout <= cout_pad, "gemm_f32_batched: bad arguments");
     const size_t x_bytes = (size_t)nb * rows_pad * k * 4, w_bytes = (size_t)nb * cout_pad * k * 4;
@@ -953,6 +1009,10 @@ int gemm_f32_batched(const float* a_mat, const float* w, int nb, int rows_pad, i
     a.H = 1; a.W = 1; a.Cin = k; a.Ho = 1; a.Wo = 1; a.Cout = cout; a.KW = 1; a.stride = 1; a.pad = 0; a.K = k;
     a.M = nb * rows_pad; a.relu = 0; a.tiles_n = 0; a.ksplit = 1; a.kchunk = k / SBK; a.partial = nullptr;
     a.clamped = nullptr; a.f32 = 1;
+    static const int b3_env = getenv("FD_BF16X3") ? atoi(getenv("FD_BF16X3")) : 0;
+    static const int b3_bal = getenv("FD_B3_BALANCE") ? atoi(getenv("FD_B3_BALANCE")) : -1;
+    if (b3 || b3_env) a.f32 = 2;
+    a.b3_balance = b3_bal >= 0 ? b3_bal : b3_balance;
     a.wbatch_tiles = rows_pad / 128;
     a.wbatch_bytes = (unsigned)((size_t)cout_pad * k * 4);
     // K <= 256 (the 256-channel stage): three workgroups per CU on 128 x 64 tiles, as for the K = 256 layers

@@ -30,7 +30,9 @@ struct SplitKArgs {
     // the weight set at byte offset b * wbatch_bytes (0 tiles: one weight set)
     int wbatch_tiles = 0;
     unsigned wbatch_bytes = 0;
-    int f32;                 // float32 operands: x, w and the "split" output are plain float32 tensors (same
+    int b3_balance = 63;     // bf16x3: percentage of a tile's K-steps accumulated as +(sum); the rest as -(sum), which
+                             // cancels the matrix unit's rounding bias (0: everything as +(sum))
+    int f32;                 // float32 operands (1; 2: with bf16x3 products): x, w and the "split" output are plain float32 tensors (same
                              // 4 bytes per element, so the same addressing; 128-byte rows of 32 floats)
 };
 
@@ -116,6 +118,79 @@ __device__ __forceinline__ void f32_mma_step(const char* stage, const int (&a_of
                 for (int ni = 0; ni < AN; ++ni)
                     acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mi][t], bv[ni][t], acc[mi][ni], 0, 0, 0);
         __builtin_amdgcn_s_setprio(0);
+    }
+}
+
+// The same K-step on the bf16 matrix cores with float32-grade products ("bf16x3"): the staged operands are
+// the same float32 rows; each value v is cut in registers into three bf16 numbers
+//     hi = bf16(v),  mid = bf16(v - hi),  lo = bf16(v - hi - mid)        (round-to-nearest-even)
+// whose sum reproduces v to 2^-27 |v| (both subtractions are exact in float32), with the float32 exponent
+// range (nothing is clamped).  A product a * b is accumulated as the six partial products down to 2^-18 of
+// its size,  lo*hi + hi*lo + mid*mid + mid*hi + hi*mid + hi*hi,  each exact in the MFMA's float32 accumulator;
+// the three dropped ones (mid*lo, lo*mid, lo*lo) are below 2^-26 |a b|, less than the rounding of a float32
+// multiply.  v_mfma_f32_16x16x32_bf16 takes 8 consecutive k per lane: the lane's two 16-byte chunks of the
+// row (part 0 and 1), i.e. the same permutation of k for both operands as in f32_mma_step.
+// NEG: the activation operand enters negated (its sign bit flipped before the cut), for callers that
+// accumulate the second half of K as -(sum) to cancel the matrix unit's rounding direction (see the kernel).
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+struct Bf16x3 {
+    u32x4 hi, mid, lo;      // 8 bf16 each
+};
+
+__device__ __forceinline__ unsigned pack_bf16(float a, float b) {
+    const f32x2 v = {a, b};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));     // v_cvt_pk_bf16_f32
+}
+
+__device__ __forceinline__ void split_bf16x3(const f32x4& p0, const f32x4& p1, Bf16x3& o, unsigned flip = 0u) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        float a = j < 2 ? p0[2 * j] : p1[2 * j - 4], b = j < 2 ? p0[2 * j + 1] : p1[2 * j - 3];
+        a = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, a) ^ flip);
+        b = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, b) ^ flip);
+        const unsigned h = pack_bf16(a, b);
+        const float ra = a - __builtin_bit_cast(float, h << 16), rb = b - __builtin_bit_cast(float, h & 0xffff0000u);
+        const unsigned m = pack_bf16(ra, rb);
+        const float sa = ra - __builtin_bit_cast(float, m << 16), sb = rb - __builtin_bit_cast(float, m & 0xffff0000u);
+        o.hi[j] = h;
+        o.mid[j] = m;
+        o.lo[j] = pack_bf16(sa, sb);
+    }
+}
+
+template <int BM, int BN>
+__device__ __forceinline__ void bf16x3_mma_step(const char* stage, const int (&a_off)[2], const int (&b_off)[2],
+                                                f32x4 (&acc)[BM / 32][BN / 32], unsigned flip = 0u) {
+    constexpr int AM = BM / 32, AN = BN / 32;
+    Bf16x3 a[AM];
+#pragma unroll
+    for (int mi = 0; mi < AM; ++mi)
+        split_bf16x3(*reinterpret_cast<const f32x4*>(stage + a_off[0] + mi * 2048),
+                     *reinterpret_cast<const f32x4*>(stage + a_off[1] + mi * 2048), a[mi], flip);
+#pragma unroll
+    for (int ni = 0; ni < AN; ++ni) {
+        Bf16x3 b;
+        split_bf16x3(*reinterpret_cast<const f32x4*>(stage + b_off[0] + ni * 2048),
+                     *reinterpret_cast<const f32x4*>(stage + b_off[1] + ni * 2048), b);
+        const bf16x8 bh = __builtin_bit_cast(bf16x8, b.hi), bm = __builtin_bit_cast(bf16x8, b.mid),
+                     bl = __builtin_bit_cast(bf16x8, b.lo);
+#pragma unroll
+        for (int mi = 0; mi < AM; ++mi) {
+            const bf16x8 ah = __builtin_bit_cast(bf16x8, a[mi].hi), am = __builtin_bit_cast(bf16x8, a[mi].mid),
+                         al = __builtin_bit_cast(bf16x8, a[mi].lo);
+            f32x4 c = acc[mi][ni];
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, bm, c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, bh, c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bm, c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, c, 0, 0, 0);
+            acc[mi][ni] = c;
+        }
     }
 }
 

@@ -57,7 +57,8 @@ struct fd_detector {
                                          // 2 = F(2x2,3x3), 0 = direct (environment variable FD_WINOGRAD)
     bool winograd_split = true;          // f16x3 precision: F(4x4,3x3) for the RPN and the 256-channel stage when
                                          // `winograd` is 4 (environment variable FD_WINOGRAD_SPLIT=0: direct)
-    int precision = FD_PRECISION_F32;      // the reference's arithmetic unless the caller opts into the split form
+    int precision = FD_PRECISION_F32;      // the reference's arithmetic unless the caller opts into another form
+    int b3_balance = 63;                   // FD_PRECISION_BF16X3: see SplitConvOut (FD_B3_BALANCE overrides; 0 = off)
     const float *bn1_scale = nullptr, *bn1_shift = nullptr;
     const float *w_cls = nullptr, *b_cls = nullptr, *w_box = nullptr, *b_box = nullptr;
     int32_t* nan_flag = nullptr;         // status block on the device: [0] NaN met by the proposal stage,
@@ -368,6 +369,8 @@ struct Plan {
         o.splitk_ws = buf(NB_SPLITK, SPLITK_FLOATS);
         o.splitk_ws_floats = SPLITK_FLOATS;
         o.clamped = d->clamped;
+        o.b3 = d->precision == FD_PRECISION_BF16X3;
+        o.b3_balance = d->b3_balance;
         return o;
     }
     void tap(const char* name, const float* p, int64_t a, int64_t b, int64_t c, int64_t e) {
@@ -583,7 +586,7 @@ static int run_unit_split(Plan& pl, const Unit& u, const char* name, const void*
             if (!pl.d->layerwise())
                 FD_TRY(conv_tail_fused_forward(c2, c3, t1, n, h, w, res, o3, pl.stream, &fused));
             if (!fused) {
-                if (wino2) FD_TRY(wino_conv_forward(u.w_conv2, t1, n, h, w, wino_v, wino_m, t2, pl.stream));
+                if (wino2) FD_TRY(wino_conv_forward(u.w_conv2, t1, n, h, w, wino_v, wino_m, t2, pl.stream, o2.b3, o2.b3_balance));
                 else if (wino2s) FD_TRY(wino_conv_forward_split(u.w_conv2, t1, n, h, w, wino_v, wino_m, t2, pl.d->clamped, pl.stream));
                 else FD_TRY(split_conv_forward(c2, t1, n, h, w, nullptr, o2, pl.stream));
                 FD_TRY(split_conv_forward(c3, t2, n, ho, wo, res, o3, pl.stream));
@@ -695,7 +698,7 @@ static int run_graph_split(Plan& pl, const uint8_t* frames, int B, int H, int W,
         SplitConvOut o1 = pl.out(), o2 = pl.out();
         o1.ysplit = hid;
         o2.y32 = rout;
-        if (wino) FD_TRY(wino_conv_forward(d->w_rpn_conv, feat, B, fh, fw, wino_v, wino_m, hid, pl.stream));
+        if (wino) FD_TRY(wino_conv_forward(d->w_rpn_conv, feat, B, fh, fw, wino_v, wino_m, hid, pl.stream, o1.b3, o1.b3_balance));
         else if (winos) FD_TRY(wino_conv_forward_split(d->w_rpn_conv, feat_split, B, fh, fw, wino_v, wino_m, hid, d->clamped, pl.stream));
         else FD_TRY(split_conv_forward(f32 ? d->f_rpn_conv : d->s_rpn_conv, feat_split, B, fh, fw, nullptr, o1, pl.stream));
         FD_TRY(split_conv_forward(f32 ? d->f_rpn_out : d->s_rpn_out, hid, B, fh, fw, nullptr, o2, pl.stream));
@@ -782,7 +785,7 @@ static int forward(fd_detector* d, const uint8_t* frames, int B, int H, int W, f
     // Both precisions run the graph of run_graph_split; FD_F32_LAYERWISE=1 selects the older float32 pass
     // that launches every layer with the register-staged fp32 kernel (comparisons only).
     static const bool legacy_f32 = getenv("FD_F32_LAYERWISE") && atoi(getenv("FD_F32_LAYERWISE")) != 0;
-    pl.f32 = d->precision == FD_PRECISION_F32;
+    pl.f32 = d->precision != FD_PRECISION_F16X3;      // float32 operand tensors (bf16x3 forms its products from them)
     const bool split = !(pl.f32 && legacy_f32);
     FD_TRY((split ? run_graph_split : run_graph)(pl, frames, B, H, W, im_scale, nullptr, nullptr, nullptr));
     for (int i = 0; i < NB_COUNT; ++i) {
@@ -825,7 +828,7 @@ __global__ __launch_bounds__(256) void boxes_to_source_kernel(const float* __res
 // and, with many proposals per frame, the ROI head's.  The f16x3 kernels have pointer-addressed forms for
 // larger tensors and take any batch.  FD_F32_PASS_FRAMES lowers the limit (tests).
 static int frames_per_pass(const fd_detector* d, int batch, int H, int W) {
-    if (d->precision != FD_PRECISION_F32) return batch;
+    if (d->precision == FD_PRECISION_F16X3) return batch;
     const long long h2 = (H - 1) / 2 + 1, w2 = (W - 1) / 2 + 1;      // stem (7x7, stride 2, pad 3)
     const long long h4 = (h2 - 1) / 2 + 1, w4 = (w2 - 1) / 2 + 1;    // max-pool (3x3, stride 2, pad 1)
     long long per_frame = std::max(h2 * w2 * FILTERS[0], h4 * w4 * FILTERS[1]) * 4;
@@ -927,9 +930,10 @@ int fd_detector_set_proposal(fd_detector* d, const fd_proposal_cfg* cfg) {
 
 int fd_detector_set_precision(fd_detector* d, int precision) {
     FD_REQUIRE(d, "fd_detector_set_precision: NULL detector");
-    FD_REQUIRE(precision == FD_PRECISION_F32 || precision == FD_PRECISION_F16X3,
+    FD_REQUIRE(precision == FD_PRECISION_F32 || precision == FD_PRECISION_F16X3 || precision == FD_PRECISION_BF16X3,
                "fd_detector_set_precision: unknown precision %d", precision);
     d->precision = precision;
+    if (const char* e = getenv("FD_B3_BALANCE")) d->b3_balance = atoi(e);
     return FD_OK;
 }
 

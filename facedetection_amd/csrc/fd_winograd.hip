@@ -445,7 +445,7 @@ bool wino_fits(const WinoConvParams& p, int batch, int h, int w) {
 }
 
 int wino_conv_forward(const WinoConvParams& p, const float* x, int batch, int h, int w, float* v_ws, float* m_ws,
-                      float* y, hipStream_t stream) {
+                      float* y, hipStream_t stream, bool b3, int b3_balance) {
     FD_REQUIRE(x && y && v_ws && m_ws && wino_fits(p, batch, h, w), "winograd convolution: bad arguments or sizes");
     const int tile = p.tile, nb = (tile + 2) * (tile + 2);
     const int th = (h + tile - 1) / tile, tw = (w + tile - 1) / tile;
@@ -461,7 +461,7 @@ int wino_conv_forward(const WinoConvParams& p, const float* x, int batch, int h,
                                w, p.cin, th, tw, T_pad, v_ws);
         FD_LAUNCH_CHECK();
     }
-    FD_TRY(gemm_f32_batched(v_ws, p.u, nb, (int)T_pad, p.cin, p.cout, p.cout_pad, m_ws, stream));
+    FD_TRY(gemm_f32_batched(v_ws, p.u, nb, (int)T_pad, p.cin, p.cout, p.cout_pad, m_ws, stream, b3, b3_balance));
     {
         ProfScope scope(stream, "wino_output", 0.0, 4.0 * p.cout * ((double)nb * T + (double)batch * h * w));
         const long long items = T * (p.cout / 4);

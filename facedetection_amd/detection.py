@@ -95,8 +95,11 @@ class Detector:
         """"f32" (default): float32 operands on the fp32 matrix cores, the reference's arithmetic.
         "f16x3": exact two-way fp16 split of both operands, three f16 MFMAs per product, float32
         accumulate -- the same error level against float64 inside the fp16 range, about twice the
-        frame rate; values that leave the range are counted and handled as ``on_clamp`` says."""
-        code = {"f32": 0, "f16x3": 1}[precision]
+        frame rate; values that leave the range are counted and handled as ``on_clamp`` says.
+        "bf16x3": the float32 tensors and kernels with every product formed on the bf16 matrix cores from exact
+        three-way bf16 splits of both operands (six partial products, float32 accumulate, float32 range, nothing
+        clamped): the error of "f32" against float64 at a higher rate."""
+        code = {"f32": 0, "f16x3": 1, "bf16x3": 2}[precision]
         _lib.check(self._lib.fd_detector_set_precision(self._h, code))
         self.precision = precision
 

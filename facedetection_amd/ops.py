@@ -132,7 +132,7 @@ def conv2d(x, weight, stride=1, pad=0, bias=None, pre_scale=None, pre_shift=None
                                                   runtime.ptr(bd), 1 if relu else 0, 4 if precision == "winograd4" else 2,
                                                   runtime.ptr(y), runtime.stream_ptr()))
         return y.cpu().numpy() if as_np else y
-    fn = _lib.lib().fd_conv2d if precision == "f32" else _lib.lib().fd_conv2d_f16x3
+    fn = {"f32": _lib.lib().fd_conv2d, "f16x3": _lib.lib().fd_conv2d_f16x3, "bf16x3": _lib.lib().fd_conv2d_bf16x3}[precision]
     _lib.check(fn(ctx.handle, runtime.ptr(xd), B, H, W, Cin, runtime.ptr(wd), Cout, kh, kw,
                   int(stride), int(pad), runtime.ptr(bd), runtime.ptr(sd), runtime.ptr(hd),
                   1 if relu else 0, runtime.ptr(rd), runtime.ptr(y), runtime.stream_ptr()))

@@ -191,6 +191,13 @@ int fd_conv2d(fd_ctx* ctx, const float* x_nhwc, int batch, int height, int width
               int cout, int kh, int kw, int stride, int pad, const float* bias, const float* pre_scale,
               const float* pre_shift, int relu, const float* residual, float* y_nhwc, void* stream);
 
+/* The same operator, same float32 tensors, with every product formed on the bf16 matrix cores from three-way bf16
+ * splits of both operands (FD_PRECISION_BF16X3, see below); cout must be a multiple of 8, tensors below 2^31 bytes. */
+int fd_conv2d_bf16x3(fd_ctx* ctx, const float* x_nhwc, int batch, int height, int width, int cin,
+                     const float* w_oihw, int cout, int kh, int kw, int stride, int pad, const float* bias,
+                     const float* pre_scale, const float* pre_shift, int relu, const float* residual,
+                     float* y_nhwc, void* stream);
+
 /* The same operator with split-precision arithmetic (FD_PRECISION_F16X3, see below); cout must be a
  * multiple of 8.  Reads the weights back to the host to choose their scale: synchronous. */
 int fd_conv2d_f16x3(fd_ctx* ctx, const float* x_nhwc, int batch, int height, int width, int cin,
@@ -222,7 +229,7 @@ typedef struct fd_param {
 int fd_detector_create(fd_ctx* ctx, const fd_param* params, int n_params, const fd_proposal_cfg* cfg,
                        fd_detector** out);
 void fd_detector_destroy(fd_detector* det);
-/* Arithmetic of the convolutions.  Both accumulate in float32 on the matrix cores.  In both, the RPN's 3x3
+/* Arithmetic of the convolutions.  All accumulate in float32 on the matrix cores.  In all, the RPN's 3x3
  * convolution and the wide stride-1 3x3 layers of the bottleneck units are computed in Winograd F(4x4,3x3)
  * form (a quarter of the multiplies; same end-to-end error against float64 as the direct form, see
  * fd_conv2d_winograd); environment variable FD_WINOGRAD=0, read by fd_detector_create, keeps every layer direct.
@@ -232,9 +239,20 @@ void fd_detector_destroy(fd_detector* det);
  *                      hi*hi + hi*lo + lo*hi on the f16 matrix cores: float32-grade results
  *                      (same error level against a float64 reference) at 16/3 of the rate.
  *                      Activations are clamped to the fp16 range (+-65504); every clamped value
- *                      is counted (fd_detector_status).  Opt-in. */
+ *                      is counted (fd_detector_status).  Opt-in.
+ *   FD_PRECISION_BF16X3 the float32 tensors, weights and kernels of FD_PRECISION_F32, but each product is formed on
+ *                      the bf16 matrix cores: both operands are cut in registers into three bf16 numbers
+ *                      (hi + mid + lo reproduces a float32 value to 2^-27 of its size, with the float32 exponent range:
+ *                      nothing is clamped) and a product is the six partial products down to 2^-18 of its size,
+ *                      accumulated in float32 -- the dropped ones are below a float32 multiply's own rounding.  The
+ *                      bf16 matrix unit rounds its sums downwards; the kernels cancel that bias by accumulating
+ *                      the last 37 % of every K loop negated.  Measured against float64 the error equals that of
+ *                      FD_PRECISION_F32 (fd_conv2d with FD_BF16X3=1 in the environment: rms error 0.85-1.15 times
+ *                      the float32 kernel's on K = 128 ... 4608, mean error below 1e-8 of the output rms), at up to
+ *                      8/3 of the fp32 matrix rate.  The fused stem keeps float32 products.  Opt-in. */
 #define FD_PRECISION_F32 0
 #define FD_PRECISION_F16X3 1
+#define FD_PRECISION_BF16X3 2
 int fd_detector_set_precision(fd_detector* det, int precision);
 
 /* Replaces the proposal settings (the reference mutates `config` and rebuilds the symbol). */

@@ -30,7 +30,7 @@ def oracle_4k(params):
     return img, ref, inter
 
 
-@pytest.mark.parametrize("precision", ["f32", "f16x3"])
+@pytest.mark.parametrize("precision", ["f32", "f16x3", "bf16x3"])
 def test_4k_frame_matches_oracle(params, oracle_4k, precision):
     from facedetection_amd.detection import Detector
     img, ref, inter = oracle_4k
@@ -50,7 +50,7 @@ def test_4k_frame_matches_oracle(params, oracle_4k, precision):
     assert np.abs(dets[:, :4] - ref[:, :4]).max(initial=0) <= 1.0
 
 
-@pytest.mark.parametrize("precision", ["f32", "f16x3"])
+@pytest.mark.parametrize("precision", ["f32", "f16x3", "bf16x3"])
 def test_dense_crowd_settings(params, precision):
     """1080p, RPN_MIN_SIZE 12, no pre-NMS cut (97 920 candidates), 6 000 rois into stage 4."""
     from facedetection_amd.detection import Detector

@@ -58,7 +58,7 @@ CONV_CASES = [
 ]
 
 
-@pytest.mark.parametrize("precision", ["f32", "f16x3"])
+@pytest.mark.parametrize("precision", ["f32", "f16x3", "bf16x3"])
 @pytest.mark.parametrize("case", CONV_CASES, ids=lambda c: "x".join(str(v) for v in c[:8]) + "-" + c[8])
 def test_conv2d_vs_float64(ops, case, precision):
     B, H, W, Cin, Cout, k, stride, pad, extras = case

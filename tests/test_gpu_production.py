@@ -61,7 +61,7 @@ def oracle64(params, frame):
     return o
 
 
-@pytest.fixture(scope="module", params=["f16x3", "f32"])
+@pytest.fixture(scope="module", params=["f16x3", "f32", "bf16x3"])
 def production_run(params, frame, request):
     """One ordinary pass (kernel selection untouched) with the tensors it materialises kept."""
     from facedetection_amd.detection import Detector
@@ -105,7 +105,7 @@ def test_graph_outputs_of_an_ordinary_pass_at_1080p(production_run, oracle64):
     np.testing.assert_array_equal(production_run["taps"]["cls_prob"].reshape(-1, 2), production_run["cls_prob"])
 
 
-@pytest.mark.parametrize("precision", ["f16x3", "f32"])
+@pytest.mark.parametrize("precision", ["f16x3", "f32", "bf16x3"])
 def test_default_detector_on_one_1080p_frame(params, frame, precision):
     """BASELINE configuration 2: Detector defaults (thresh 0.8, nms 0.3, min size 50, 1000 / 10 proposals)."""
     from facedetection_amd.detection import Detector
@@ -139,7 +139,7 @@ def _frames_1080p(n, seed=7):
     return out
 
 
-@pytest.mark.parametrize("precision", ["f16x3", "f32"])
+@pytest.mark.parametrize("precision", ["f16x3", "f32", "bf16x3"])
 def test_pipeline_of_32_frames_equals_frame_by_frame_detection(params, precision):
     """BASELINE configuration 3 at a size the test can afford: 32 frames of 1080p through
     FramePipeline(streams=2, micro_batch=8) -- the benchmark's code path -- against
