@@ -14,8 +14,10 @@ The line's headline (`value`, `dtype`, `roofline`) is measured with float32 oper
 matrix cores -- the reference's arithmetic.  After the timed region the same process measures, as
 sub-records under `configs`, the other configurations of the benchmark definition at the same
 precision (single 1080p frame latency, 4K frames, the dense-crowd stress setting) and the
-front-end resize, each HBM-bound stage with its fraction of the HBM peak; `--split-record` adds
-the opt-in f16x3 arithmetic (not the reference's: 22 significant bits, fp16 range) as `f16x3`.
+front-end resize, each HBM-bound stage with its fraction of the HBM peak, and as `bf16x3` the opt-in
+three-way bf16 split (float32 tensors and range, products on the bf16 matrix cores; own kernels, own
+roofline entry); `--split-record` adds the opt-in f16x3 arithmetic (not the reference's: 22 significant
+bits, fp16 range) as `f16x3`.
 
 Launching: `python bench.py --gpus N` with N > 1 and no RANK in the environment starts N ranks
 itself (fresh processes, one per GPU, before this process touches a GPU); under
@@ -70,6 +72,8 @@ GFLOP_PER_FRAME = 354.5          # 1080p, post_nms_top_n = 10: 2 x gmac_per_fram
 PEAK_FP32_MATRIX_TFLOPS = 157.3  # v_mfma_f32_32x32x2_f32, dense
 PEAK_F16_MATRIX_TFLOPS = 2500.0  # v_mfma_f32_16x16x32_f16, dense
 PEAK_HBM_GBS = 8000.0            # HBM3E peak
+B3_DTYPE = ("f32 tensors; every product from exact three-way bf16 splits of both operands (6 bf16 MFMAs per product, "
+            "f32 accumulate, f32 exponent range)")
 PROP = dict(pre_nms_top_n=1000, post_nms_top_n=10, nms_thresh=0.7, min_size=50)
 PMC_BATCH = 16                   # default micro-batch; the committed PMC passes are taken at it (16 frames' stage-1
                                  # tensors are the largest the 2^31-byte buffer-addressed kernels reach)
@@ -444,6 +448,9 @@ def main():
     ap.add_argument("--split-record", action="store_true",
                     help="also time the opt-in f16x3 arithmetic (not the reference's) and report it as the sub-record f16x3")
     ap.add_argument("--no-split-record", action="store_true", help="(default; kept for older command lines)")
+    ap.add_argument("--no-b3-record", action="store_true",
+                    help="skip the sub-record bf16x3 (float32 tensors, every product from three-way bf16 splits on the bf16 "
+                         "matrix cores; its kernels carry their own names, so the float32 kernels' trace averages are unaffected)")
     ap.add_argument("--no-config-records", action="store_true",
                     help="skip the sub-records of the other configurations (single-frame latency, 4K, dense crowd, resize)")
     ap.add_argument("--check-frames", type=int, default=2, help="frames compared with the float64 oracle")
@@ -669,6 +676,8 @@ def main():
     # of the two streams overlap, so per-kernel durations there say nothing about a kernel's own roofline)
     head2 = measure(args.precision, 2) if (args.two_streams and args.streams == 1 and n_streams >= 2) else None
     sub = measure("f16x3", args.split_streams) if do_split else None
+    do_b3 = args.precision == "f32" and not args.no_b3_record and (H, W) == (1080, 1920)
+    sub3 = measure("bf16x3", 1) if do_b3 else None
     direct_elapsed = measure_direct() if (args.direct_record and args.precision == "f32") else None
 
     # hand-off (untimed): per-frame detection lists gathered in global frame order
@@ -708,7 +717,7 @@ def main():
         "scaling": "weak",
         "vs_baseline": None,
         "dtype": ("f32 operands as fp16 hi+lo pairs (22 significant bits, fp16 range), 3 f16 MFMAs per product, f32 accumulate"
-                  if split_head else "f32"),
+                  if split_head else B3_DTYPE if args.precision == "bf16x3" else "f32"),
         "data": "synthetic",
         "config": {"workload": "batch of %d synthetic %s frames per GPU resident in HBM, full Faster R-CNN "
                                "(ResNet-50) cascade, micro-batches of %d on %d HIP stream(s)"
@@ -751,7 +760,7 @@ def main():
     acc = None
     if args.check_frames > 0 and not split_head:
         acc = accuracy_vs_float64(pipe, frames, min(args.check_frames, args.frames),
-                                  (args.precision, "f16x3") if do_split else (args.precision,))
+                                  (args.precision,) + (("f16x3",) if do_split else ()) + (("bf16x3",) if sub3 else ()))
         line["accuracy_vs_float64"] = acc[args.precision]
     if sub:
         sfps = total_frames / sub["elapsed"]
@@ -766,6 +775,15 @@ def main():
         if acc:
             rec.update(acc["f16x3"])
         line["f16x3"] = rec
+    if sub3:
+        b3fps = total_frames / sub3["elapsed"]
+        b3roof, b3table = roofline_of(sub3, b3fps)
+        rec = {"value": round(b3fps, 3), "unit": "frames/s", "ms_per_step": round(1000.0 * sub3["elapsed"] / args.steps, 3),
+               "streams": 1, "dtype": B3_DTYPE, "roofline": b3roof, "kernels_single_stream_step": (b3table or [])[:12],
+               "note": "opt-in arithmetic (precision=\"bf16x3\"), reported beside the float32 headline, never as it"}
+        if acc:
+            rec.update(acc["bf16x3"])
+        line["bf16x3"] = rec
     if not args.no_config_records and not split_head and (H, W) == (1080, 1920):
         pipe.set_precision(args.precision)
         line["configs"] = config_records(pipe.detectors[0], frames, device)

@@ -925,10 +925,24 @@ static int split_conv_dispatch(const SplitConvParams& p, const void* x_split, co
             else FD_TRY((launch_split_glds<64, 64, 4, 4, true>(a, x_bytes, w_bytes, stream)));
             return split_k_finish(a, stream);
         }
+        // FD_F32_TILE / FD_F32_TILE_PRE (probes): one tile shape for every layer of the kernel family that can take it
+        static const int tile_env = getenv("FD_F32_TILE") ? atoi(getenv("FD_F32_TILE")) : 0;
+        static const int tile_pre_env = getenv("FD_F32_TILE_PRE") ? atoi(getenv("FD_F32_TILE_PRE")) : 0;
         if (pre_scale) {
+            if (tile_pre_env == 1 && s.cout > 64) return launch_split_reg<128, 128, REG_PRE, true>(a, x_bytes, w_bytes, stream);
+            if (tile_pre_env == 2) return launch_split_reg<128, 64, REG_PRE, true>(a, x_bytes, w_bytes, stream);
+            if (tile_pre_env == 3) return launch_split_reg<64, 64, REG_PRE, true>(a, x_bytes, w_bytes, stream);
             if (s.cout > 64 && t128 >= 384) return launch_split_reg<128, 128, REG_PRE, true>(a, x_bytes, w_bytes, stream);
-            if (t12864 >= 384) return launch_split_reg<128, 64, REG_PRE, true>(a, x_bytes, w_bytes, stream);
+            // a single frame's 64-channel layers (1 013 tiles of 128 x 64): 59 -> 52 us on 64 x 64 tiles; from two
+            // frames on the taller tile is as fast or faster
+            if (t12864 >= (s.cout <= 64 ? 1536 : 384)) return launch_split_reg<128, 64, REG_PRE, true>(a, x_bytes, w_bytes, stream);
             return launch_split_reg<64, 64, REG_PRE, true>(a, x_bytes, w_bytes, stream);
+        }
+        if (a.f32 != 2 && tile_env) {
+            if (tile_env == 1 && s.cout > 64) return launch_split_glds<128, 128, 2, 4, true>(a, x_bytes, w_bytes, stream);
+            if (tile_env == 2 && s.cout > 64) return launch_split_glds<128, 64, 2, 4, true, 3>(a, x_bytes, w_bytes, stream);
+            if (tile_env == 3) return launch_split_glds<128, 64, 3, 4, true>(a, x_bytes, w_bytes, stream);
+            if (tile_env == 4) return launch_split_glds<64, 64, 4, 4, true>(a, x_bytes, w_bytes, stream);
         }
         if (a.f32 == 2) {
             // bf16x3 products: a K-step lasts 3/8 as long as with float32 products, so the two-stage four-wave tiles
@@ -946,9 +960,21 @@ static int split_conv_dispatch(const SplitConvParams& p, const void* x_split, co
         // them better than two on 128 x 128: 107-117 -> 125 TF on those layers, +1.6 % frames/s.  Shorter K
         // (the layers bound by their own output traffic; also tried: 64 x 64 tiles at five workgroups per CU)
         // and longer K measured no gain.
+        // Measured again layer by layer at micro-batch 16 with one tile shape forced per run (FD_F32_TILE): the
+        // three-workgroup tile is also 3-5 % faster on the K = 128 layers of the 128-channel stage (789 -> 745 us) and
+        // on the K = 512 projection layers (1 073 -> 1 032 us), which is +0.2 % frames/s over the whole pass -- inside
+        // the box-to-box spread, so those layers stay on 128 x 128 (FD_F32_SHORTK=512 moves them).
+        // Small grids (single frames): a launch whose last round of tiles is mostly empty takes the shape that fills
+        // its rounds better -- 1 024 tiles of 128 x 64 are 1.33 rounds of 768 resident workgroups, the same layer as
+        // 512 tiles of 128 x 128 is exactly one round of 512 (50 -> 43.5 us).  The tile shape does not change the
+        // order in which an output element accumulates over K, so results do not depend on the choice.
         static const int shortk = getenv("FD_F32_SHORTK") ? atoi(getenv("FD_F32_SHORTK")) : 256;
-        if (a.K > 128 && a.K <= shortk && s.cout > 64 && t12864 >= 768)
-            return launch_split_glds<128, 64, 2, 4, true, 3>(a, x_bytes, w_bytes, stream);
+        if ((a.K > 128 || shortk > 256) && a.K <= shortk && s.cout > 64 && t12864 >= 768) {
+            const double fill_o3 = (double)t12864 / ((double)ceil_div(t12864, 768) * 768.0);
+            const double fill_128 = (double)t128 / ((double)ceil_div(t128, 512) * 512.0);
+            if (!(fill_o3 < 0.8 && fill_128 >= 0.95 && t128 >= 384))
+                return launch_split_glds<128, 64, 2, 4, true, 3>(a, x_bytes, w_bytes, stream);
+        }
         if (s.cout > 64 && t128 >= 384) return launch_split_glds<128, 128, 2, 4, true>(a, x_bytes, w_bytes, stream);
         if (t12864 >= 384) return launch_split_glds<128, 64, 3, 4, true>(a, x_bytes, w_bytes, stream);
         return launch_split_glds<64, 64, 4, 4, true>(a, x_bytes, w_bytes, stream);
@@ -1017,8 +1043,22 @@ int gemm_f32_batched(const float* a_mat, const float* w, int nb, int rows_pad, i
     a.wbatch_bytes = (unsigned)((size_t)cout_pad * k * 4);
     // K <= 256 (the 256-channel stage): three workgroups per CU on 128 x 64 tiles, as for the K = 256 layers
     // of split_conv_dispatch (+0.5 % frames/s)
+    static const int gemm_tile = getenv("FD_F32_GEMM_TILE") ? atoi(getenv("FD_F32_GEMM_TILE")) : 0;     // probes
+    if (gemm_tile == 1) return launch_split_glds<128, 128, 2, 4, true>(a, x_bytes, w_bytes, stream);
+    if (gemm_tile == 2) return launch_split_glds<128, 64, 2, 4, true, 3>(a, x_bytes, w_bytes, stream);
+    if (gemm_tile == 3) return launch_split_glds<128, 64, 3, 4, true>(a, x_bytes, w_bytes, stream);
+    if (gemm_tile == 4) {
+        a.wbatch_tiles = rows_pad / 64;
+        return launch_split_glds<64, 64, 4, 4, true>(a, x_bytes, w_bytes, stream);
+    }
     static const int gemm_o3 = getenv("FD_F32_GEMM_O3") ? atoi(getenv("FD_F32_GEMM_O3")) : 1;
     if (gemm_o3 && k <= 256) return launch_split_glds<128, 64, 2, 4, true, 3>(a, x_bytes, w_bytes, stream);
+    // long K on a small grid (the RPN's layer for a single frame: 576 tiles of 128 x 128 are 1.13 rounds of 512
+    // resident workgroups): the three-workgroup tile fills its rounds better (197 -> 164 us)
+    const long long t128 = (long long)(a.M / 128) * ceil_div(cout, 128), t12864 = (long long)(a.M / 128) * ceil_div(cout, 64);
+    const double fill_128 = (double)t128 / ((double)ceil_div(t128, 512) * 512.0);
+    const double fill_o3 = (double)t12864 / ((double)ceil_div(t12864, 768) * 768.0);
+    if (gemm_o3 && fill_128 < 0.7 && fill_o3 > fill_128) return launch_split_glds<128, 64, 2, 4, true, 3>(a, x_bytes, w_bytes, stream);
     return launch_split_glds<128, 128, 2, 4, true>(a, x_bytes, w_bytes, stream);
 }
 

@@ -76,6 +76,12 @@ def test_bench_prints_one_json_line_with_the_contract_fields():
     assert s["max_abs_score_err_vs_f64"] <= 1e-4 and s["max_box_err_px"] <= 0.5
     assert s["clamped_values"] == 0 and s["clamped_values_last_timed_step"] == 0
     _check_roofline(s["roofline"])
+    # the opt-in three-way bf16 split: float32 tensors and range, its own kernels and matrix peak (2500 / 6)
+    b = d["bf16x3"]
+    assert b["value"] > 0 and b["clamped_values"] == 0 and "bf16" in b["dtype"]
+    assert b["max_abs_score_err_vs_f64"] <= 1e-4 and b["max_box_err_px"] <= 0.5
+    _check_roofline(b["roofline"])
+    assert b["roofline"]["kernel"].startswith("conv_b3") and abs(b["roofline"]["peak"] - 2500.0 / 6) < 0.1
     # the same float32 pass without the Winograd form of the wide 3x3 layers, reported next to the headline
     dc = d["f32_direct_convolutions"]
     assert dc["dtype"] == "f32" and 0 < dc["value"] <= d["value"] * 1.05

@@ -13,7 +13,7 @@ cd /tmp && export TMPDIR=/tmp
 timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -- python3 $R/bench.py > $OUT/bench_under_rocprof.json 2> $OUT/kt.err
 cp $(ls $OUT/kt/*/*kernel_stats.csv | head -1) $OUT/kernel_stats.csv
 rm -f $OUT/kt/*/*kernel_trace.csv
-SHORT="--frames 16 --steps 1 --warmup 1 --no-cpu-baseline --no-profile --check-frames 0 --split-streams 1"
+SHORT="--frames 16 --steps 1 --warmup 1 --no-cpu-baseline --no-profile --check-frames 0 --split-streams 1 --no-b3-record"
 timeout -s KILL 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 $R/bench.py $SHORT > $OUT/pmc_fetch.json 2> $OUT/pmc_fetch.err
 timeout -s KILL 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 $R/bench.py $SHORT > $OUT/pmc_write.json 2> $OUT/pmc_write.err
 cd $R
@@ -21,7 +21,7 @@ python3 tools/pmc_summary.py $(ls $OUT/pmc_fetch/*/*counter_collection.csv | hea
 rm -rf $OUT/pmc_fetch $OUT/pmc_write $OUT/kt
 # the float32 pass alone (warm-up + one step of 16 frames = 32 frames): traffic of the whole pass per frame
 cd /tmp
-SHORT32="--frames 16 --steps 1 --warmup 1 --no-cpu-baseline --no-profile --check-frames 0 --no-split-record"
+SHORT32="--frames 16 --steps 1 --warmup 1 --no-cpu-baseline --no-profile --check-frames 0 --no-split-record --no-b3-record"
 timeout -s KILL 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch32 -- python3 $R/bench.py $SHORT32 > $OUT/pmc_fetch32.json 2> $OUT/pmc_fetch32.err
 timeout -s KILL 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write32 -- python3 $R/bench.py $SHORT32 > $OUT/pmc_write32.json 2> $OUT/pmc_write32.err
 cd $R
