@@ -901,6 +901,8 @@ static int split_conv_dispatch(const SplitConvParams& p, const void* x_split, co
     static const int b3_bal = getenv("FD_B3_BALANCE") ? atoi(getenv("FD_B3_BALANCE")) : -1;
     if (p.f32 && (out.b3 || b3_env)) a.f32 = 2;
     a.b3_balance = b3_bal >= 0 ? b3_bal : out.b3_balance;
+    static const int stream_res_env = getenv("FD_STREAM_RES") ? atoi(getenv("FD_STREAM_RES")) : 0;
+    a.stream_res = stream_res_env;
     FD_REQUIRE(!(stem && pre_scale), "split conv: the stem takes the staged image only");
     // the buffer-addressed kernels use 32-bit byte offsets below 2^31 into both tensors
     const size_t x_bytes = (size_t)batch * h * w * s.cin * 4, w_bytes = s.packed_floats() * 4;
@@ -960,6 +962,7 @@ static int split_conv_dispatch(const SplitConvParams& p, const void* x_split, co
         // them better than two on 128 x 128: 107-117 -> 125 TF on those layers, +1.6 % frames/s.  Shorter K
         // (the layers bound by their own output traffic; also tried: 64 x 64 tiles at five workgroups per CU)
         // and longer K measured no gain.
+        if (a.f32 == 1 && conv_panel_applies(a)) return conv_panel_forward(a, x_bytes, w_bytes, stream);
         // Measured again layer by layer at micro-batch 16 with one tile shape forced per run (FD_F32_TILE): the
         // three-workgroup tile is also 3-5 % faster on the K = 128 layers of the 128-channel stage (789 -> 745 us) and
         // on the K = 512 projection layers (1 073 -> 1 032 us), which is +0.2 % frames/s over the whole pass -- inside

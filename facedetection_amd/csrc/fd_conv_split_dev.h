@@ -32,9 +32,15 @@ struct SplitKArgs {
     unsigned wbatch_bytes = 0;
     int b3_balance = 63;     // bf16x3: percentage of a tile's K-steps accumulated as +(sum); the rest as -(sum), which
                              // cancels the matrix unit's rounding bias (0: everything as +(sum))
+    int stream_res = 0;      // residual values of large tensors are read with streaming loads
     int f32;                 // float32 operands (1; 2: with bf16x3 products): x, w and the "split" output are plain float32 tensors (same
                              // 4 bytes per element, so the same addressing; 128-byte rows of 32 floats)
 };
+
+// Row-panel kernel for the short-K 1x1 layers of the float32 pass (fd_conv_panel.hip): whether it takes the layer
+// described by `a` (tiles_n / ksplit already set), and its launch.
+bool conv_panel_applies(const SplitKArgs& a);
+int conv_panel_forward(const SplitKArgs& a, size_t x_bytes, size_t w_bytes, hipStream_t stream);
 
 constexpr int SBK = 32;      // k per K-step
 constexpr int SLDK = 36;     // staged row: 128 B of data + 16 B pad, in dwords
@@ -265,6 +271,7 @@ __device__ __forceinline__ void split_epilogue16_rows(const SplitKArgs& a, float
     f32x4 ps0 = {1.f, 1.f, 1.f, 1.f}, ps1 = ps0, pt0 = {0.f, 0.f, 0.f, 0.f}, pt1 = pt0;
     // float32 outputs larger than the memory-side cache are written with streaming stores
     const bool stream_out = (long long)a.M * a.Cout > (80ll << 20);
+    const bool stream_res = stream_out && a.stream_res;
     const bool post = a.ysplit && a.post_scale && col_ok;
     if (post) {
         ps0 = *reinterpret_cast<const f32x4*>(a.post_scale + gcol);
@@ -288,8 +295,13 @@ __device__ __forceinline__ void split_epilogue16_rows(const SplitKArgs& a, float
                 res1[ps] = res0[ps];
                 if (row >= 0 && col_ok) {
                     const float* rp = a.res + (size_t)row * a.Cout + gcol;
-                    res0[ps] = *reinterpret_cast<const f32x4*>(rp);
-                    res1[ps] = *reinterpret_cast<const f32x4*>(rp + 4);
+                    if (stream_res) {
+                        res0[ps] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(rp));
+                        res1[ps] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(rp + 4));
+                    } else {
+                        res0[ps] = *reinterpret_cast<const f32x4*>(rp);
+                        res1[ps] = *reinterpret_cast<const f32x4*>(rp + 4);
+                    }
                 }
             }
         }
