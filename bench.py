@@ -122,9 +122,9 @@ def pmc_traffic(kernel):
     if family == "igemm":
         want = re.compile(r"conv_igemm_kernel<%s, %s, false>" % (bm, bn))
     elif pre:       # BatchNorm-on-load kernel: <BM, BN, mode 0, float32 operands?>
-        want = re.compile(r"conv_split_reg_kernel<%s, %s, 0, %s>" % (bm, bn, "true" if family == "f32" else "false"))
-    else:           # direct-to-LDS kernel: <BM, BN, stages, waves, float32 operands?, workgroups per CU>
-        want = re.compile(r"conv_split_glds_kernel<%s, %s, \d+, \d+, %s, %s>" % (bm, bn, "true" if family == "f32" else "false", occ))
+        want = re.compile(r"conv_split_reg_kernel<%s, %s, 0, %s(, false)?>" % (bm, bn, "true" if family == "f32" else "false"))
+    else:           # direct-to-LDS kernel: <BM, BN, stages, waves, float32 operands?, workgroups per CU, bf16x3 products?>
+        want = re.compile(r"conv_split_glds_kernel<%s, %s, \d+, \d+, %s, %s(, false)?>" % (bm, bn, "true" if family == "f32" else "false", occ))
     for kname, row in doc["kernels"].items():
         if want.search(kname):
             return row["hbm_bytes_per_launch"], "HBM bytes per launch from %s (kernel set %s)" % (name, build)
