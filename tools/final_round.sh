@@ -15,19 +15,19 @@ timeout -k 10 200 python3 tools/frontend_bench.py 128 > $OUT/frontend_128.json 2
 timeout -k 10 300 python3 tools/time_configs.py f16x3 > $OUT/cfg_split.txt 2>&1
 timeout -k 10 300 python3 tools/time_configs.py f32 > $OUT/cfg_f32.txt 2>&1
 cd /tmp && export TMPDIR=/tmp
-timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d $OUT/kt2 -- python3 $R/bench.py --frames 16 --steps 1 --warmup 1 --no-cpu-baseline --no-profile --check-frames 0 --no-split-record --no-b3-record > $OUT/b16.json 2> $OUT/b16.err
+timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d $OUT/kt2 -- python3 $R/bench.py --frames 16 --steps 1 --warmup 1 --no-cpu-baseline --no-profile --check-frames 0 --no-split-record --no-b3-record --no-config-records > $OUT/b16.json 2> $OUT/b16.err
 cd $R
 python3 tools/conv_layer_report.py $(ls $OUT/kt2/*/*kernel_trace.csv | head -1) 16 f32 > $OUT/layers_f32.txt 2>&1 || true
 rm -rf $OUT/kt2
 cd /tmp
-timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d $OUT/kt3 -- python3 $R/bench.py --precision f16x3 --streams 1 --frames 16 --steps 1 --warmup 1 --no-cpu-baseline --no-profile --check-frames 0 --no-split-record --no-b3-record > $OUT/b16s.json 2> $OUT/b16s.err
+timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d $OUT/kt3 -- python3 $R/bench.py --precision f16x3 --streams 1 --frames 16 --steps 1 --warmup 1 --no-cpu-baseline --no-profile --check-frames 0 --no-split-record --no-b3-record --no-config-records > $OUT/b16s.json 2> $OUT/b16s.err
 cd $R
 python3 tools/conv_layer_report.py $(ls $OUT/kt3/*/*kernel_trace.csv | head -1) 16 f16x3 > $OUT/layers_f16x3.txt 2>&1 || true
 rm -rf $OUT/kt3
 # SQ counters of one float32 micro-batch (one --pmc pass), HBM traffic of the front-end kernels (two passes), and the
 # float32 pass with the frames uploaded from pinned host memory inside the timed region
 cd /tmp
-SHORT="--frames 16 --steps 1 --warmup 1 --no-cpu-baseline --no-profile --check-frames 0 --no-split-record --no-b3-record"
+SHORT="--frames 16 --steps 1 --warmup 1 --no-cpu-baseline --no-profile --check-frames 0 --no-split-record --no-b3-record --no-config-records"
 timeout -s KILL 120 rocprofv3 --pmc SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_INSTS_LDS GRBM_GUI_ACTIVE --output-format csv -d $OUT/sq -- python3 $R/bench.py $SHORT > $OUT/sq.json 2> $OUT/sq.err
 cp $(ls $OUT/sq/*/*counter_collection.csv | head -1) $OUT/sq_counters_f32.csv
 rm -rf $OUT/sq

@@ -9,7 +9,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1]
 src, dst = os.path.join(ROOT, "gpurun_out", tag), os.path.join(ROOT, "profiles")
-for name in ("kernel_stats.csv", "bench.json", "bench_under_rocprof.json", "pmc_traffic.json", "bench_two_streams.json",
+for name in ("kernel_stats.csv", "kernel_stats_headline.csv", "bench_headline_under_rocprof.json", "bench.json", "bench_under_rocprof.json", "pmc_traffic.json", "bench_two_streams.json",
              "frontend.json", "frontend_128.json", "bench_direct.json", "bench_from_host.json", "frontend_pmc_traffic.json", "pmc_traffic_f32.json"):
     shutil.copy(os.path.join(src, name), os.path.join(dst, "%s_%s" % (tag, name)))
 for name in ("layers_f32.txt", "layers_f16x3.txt"):
@@ -44,8 +44,12 @@ for name in ("bench.json", "bench_under_rocprof.json"):
     print(name, d["value"], "fps;", r["kernel"], r["achieved"], "TF frac", r["frac"], "traffic", r["traffic"], "pipeline",
           r["pipeline_tflops"], r["pipeline_frac"], "executed", r["pipeline_executed_tflops"], r["pipeline_executed_frac"],
           "avg launch ms", r["avg_launch_ms"], "launches", r["launches"], "build", d["config"]["library_build"])
-    print("  accuracy", d.get("accuracy_vs_float64"), "| f16x3", d["f16x3"]["value"], d["f16x3"]["roofline"]["frac"],
-          d["f16x3"]["roofline"]["isolated"]["frac"], "| cpu", d["cpu_baseline"]["value"])
+    print("  accuracy", d.get("accuracy_vs_float64"), "| bf16x3", d["bf16x3"]["value"], d["bf16x3"]["roofline"]["frac"],
+          d["bf16x3"]["max_abs_score_err_vs_f64"], "| cpu", d["cpu_baseline"]["value"])
+    c = d["configs"]
+    print("  configs: latency", c["latency_1080p"]["ms"], c["latency_1080p"]["ms_back_to_back"], "| 4K", c["frame_4k"]["value"],
+          c["frame_4k"]["ms_single_frame"], "| crowd", c["dense_crowd"]["ms"], "| resize", c["frontend_resize"]["us_per_launch"],
+          c["frontend_resize"]["frac"])
 d = json.load(open(os.path.join(dst, "%s_bench_two_streams.json" % tag)))
 print("two streams", d["value"], d["two_streams"]["value"])
 d = json.load(open(os.path.join(dst, "%s_bench_from_host.json" % tag)))
