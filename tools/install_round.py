@@ -41,8 +41,8 @@ for a, b in (("cfg_split.txt", "configs_f16x3.json"), ("cfg_f32.txt", "configs_f
 for name in ("bench.json", "bench_under_rocprof.json"):
     d = json.load(open(os.path.join(dst, "%s_%s" % (tag, name))))
     r = d["roofline"]
-    print(name, d["value"], "fps;", r["kernel"], r["achieved"], "TF frac", r["frac"], "traffic", r["traffic"], "pipeline",
-          r["pipeline_tflops"], r["pipeline_frac"], "executed", r["pipeline_executed_tflops"], r["pipeline_executed_frac"],
+    print(name, d["value"], "fps;", r["kernel"], r["achieved"], "TF frac", r["frac"], "traffic", r["traffic"], "direct-equivalent",
+          r["pipeline_direct_equivalent_tflops"], "executed", r["pipeline_executed_tflops"], r["pipeline_executed_frac"],
           "avg launch ms", r["avg_launch_ms"], "launches", r["launches"], "build", d["config"]["library_build"])
     print("  accuracy", d.get("accuracy_vs_float64"), "| bf16x3", d["bf16x3"]["value"], d["bf16x3"]["roofline"]["frac"],
           d["bf16x3"]["max_abs_score_err_vs_f64"], "| cpu", d["cpu_baseline"]["value"])
@@ -52,6 +52,9 @@ for name in ("bench.json", "bench_under_rocprof.json"):
           c["frontend_resize"]["frac"])
 d = json.load(open(os.path.join(dst, "%s_bench_two_streams.json" % tag)))
 print("two streams", d["value"], d["two_streams"]["value"])
+d = json.load(open(os.path.join(dst, "%s_bench_headline_under_rocprof.json" % tag)))
+print("headline alone under rocprof", d["value"], d["roofline"]["kernel"], d["roofline"]["avg_launch_ms"], d["roofline"]["launches"])
+print("hbm_whole_pass", json.load(open(os.path.join(dst, "%s_bench.json" % tag))).get("hbm_whole_pass"))
 d = json.load(open(os.path.join(dst, "%s_bench_from_host.json" % tag)))
 print("from host", d["value"], d["config"]["library_build"])
 d = json.load(open(os.path.join(dst, "%s_frontend_pmc_traffic.json" % tag)))
