@@ -24,6 +24,7 @@ SOURCES = [
     ("fd_conv_split.hip", []),
     ("fd_conv_fused.hip", []),
     ("fd_conv_panel.hip", []),
+    ("fd_conv_tailw.hip", []),
     ("fd_winograd.hip", []),
     ("fd_detector.hip", []),
 ]

@@ -1,0 +1,336 @@
+// Bottleneck tail of the 64-channel stage with the 3x3 convolution in Winograd F(2x2, 3x3) form, float32:
+//   t2 = relu(conv3x3(t1) + b2)      (64 -> 64, stride 1, pad 1; BatchNorm folded into the weights)
+//   y  = conv1x1(t2) + residual      (64 -> cout)
+// in one kernel, like conv_tail_fused_kernel, but with 4/9 of the 3x3's multiplies.  Unlike the stand-alone
+// Winograd layers (fd_winograd.hip) nothing of the Winograd domain ever exists in memory:
+//   * a workgroup owns an 8 x 16 pixel tile = 4 x 8 output patches of 2 x 2; its 10 x 18 pixel input patch goes
+//     to LDS once by LDS-DMA (two K-step planes of 192 rows x 128 B, the usual swizzled row image, zeros outside
+//     the picture);
+//   * the input transform V = B^T d B happens in registers, on the MFMA's activation fragments: a lane reads the
+//     two input rows a transform row i combines (8 float4 per 16-channel part), forms their combination and from it
+//     the fragments of the four transform columns j -- two LDS reads and four additions per fragment;
+//   * the 16 GEMMs M[i][j] = V[i][j] U[i][j]^T (32 patches x 64 channels x K = 64 each) run with the transformed
+//     weights streamed from L2 through two LDS stages, 8 KB per GEMM and K half; wave (wm, wx) owns 16 patches and
+//     the transform rows i = 2 wx, 2 wx + 1, i.e. 8 of the 16 accumulator sets (128 registers);
+//   * the output transform Y = A^T M A is linear in M, so each wave reduces its own 8 GEMMs in registers and the
+//     two waves of a patch block add their halves through LDS; bias + ReLU, and t2 lands in LDS as the A operand
+//     of the 1x1, which then runs exactly as in conv_tail_fused_kernel (64 output channels at a time, residual
+//     values requested ahead, transposed epilogue).
+// F(2x2, 3x3)'s transforms are additions and halvings only: against float64 its error is the direct form's
+// (fd_winograd.hip).  Results differ from conv_tail_fused_kernel's in the last bits.
+#include "fd_conv_split_dev.h"
+
+#include <cstdlib>
+#include <vector>
+
+namespace fd {
+
+struct TailWinoArgs {
+    const float* x;        // t1 [B][H][W][64], activated
+    const float* u;        // transformed weights [16][2][64][32]: GEMM xi = 4 i + j, K half, output channel, channel
+    const float* bias2;    // [64]
+    SplitKArgs c;          // the 1x1: w, bias, res, y32, ysplit, post_scale / post_shift, Cout, M, w_inv_scale
+    int H, W, tiles_x, tiles_y;
+    unsigned x_bytes, u_bytes, w3_bytes;
+};
+
+__global__ __launch_bounds__(256, 2) void conv_tail_wino_kernel(TailWinoArgs k) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    constexpr int BM = 128, BN = 64, MID = 64;
+    using T = SplitTile<BM, BN>;
+    using E = SplitEpi<BM, BN>;
+    constexpr int PW = 18, PPIX = 180, PROWS = 192;
+    constexpr int PLANE = PROWS * 128;                  // bytes per K-half plane of the input patch
+    constexpr int D_BYTES = 2 * PLANE;                  // 48 KB
+    constexpr int U_OFF = D_BYTES, U_MAT = 64 * 128;    // one GEMM's weights for one K half: 8 KB
+    constexpr int U_STAGE = 2 * U_MAT;                  // both wave columns
+    constexpr int SMEM_BYTES = U_OFF + 2 * U_STAGE;     // 80 KB
+    constexpr int X_OFF = 0;                            // exchange of the output transform's halves (32 KB)
+    constexpr int A_OFF = U_OFF;                        // t2 as the 1x1's A operand: 2 K-steps x 128 rows x 128 B
+    constexpr int CS_BYTES = 20 * 1024;                 // epilogue staging / weight chunk of the 1x1, at offset 0
+    static_assert(SMEM_BYTES == 80 * 1024 && T::EPI * 4 <= CS_BYTES && CS_BYTES <= A_OFF &&
+                      A_OFF + (MID / 32) * BM * 128 <= SMEM_BYTES && 2 * 4 * 16 * 64 * 4 <= D_BYTES,
+                  "LDS plan");
+    __shared__ __attribute__((aligned(16))) float smem[SMEM_BYTES / 4];
+    char* const sbytes = reinterpret_cast<char*>(smem);
+
+    const SplitKArgs& c = k.c;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wx = wave & 1;
+    int wgid;
+    {
+        const int nwg = gridDim.x, bid = blockIdx.x;
+        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+        wgid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    }
+    const int H = k.H, W = k.W;
+    const int per_img = k.tiles_x * k.tiles_y;
+    const int img = wgid / per_img;
+    const int trem = wgid - img * per_img;
+    const int tyi = trem / k.tiles_x, txi = trem - tyi * k.tiles_x;
+    const int y0 = tyi * 8, x0 = txi * 16;
+
+    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)k.x, 0, k.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ur = __builtin_amdgcn_make_buffer_rsrc((void*)k.u, 0, k.u_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t w3r = __builtin_amdgcn_make_buffer_rsrc((void*)c.w, 0, k.w3_bytes, 0x00020000);
+    constexpr unsigned OOB = 0x80000000u;
+
+    const int frow = lane & 15, fh = lane >> 4;
+    const int sw = (frow >> 1) & 7;
+    const int lrow = lane >> 3, lpos = lane & 7;
+
+    // ---- phase 0: the input patch, 24 pieces of 8 rows per plane (rows 180..191 and pixels outside the picture: zeros)
+#pragma unroll
+    for (int i = 0; i < 12; ++i) {
+        const int q = wave + 4 * i;                  // 0..47, uniform
+        const int h = q / 24, grp = q - h * 24;
+        const int r = grp * 8 + lrow;
+        const int py = r / PW, px = r - py * PW;
+        const int gy = y0 - 1 + py, gx = x0 - 1 + px;
+        const bool ok = r < PPIX && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
+        const unsigned vo = ok ? (unsigned)(((img * H + gy) * W + gx) * (MID * 4) + h * 128 + ((lpos ^ ((r >> 1) & 7)) * 16)) : OOB;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (__attribute__((address_space(3))) void*)(sbytes + h * PLANE + grp * 1024),
+                                                 16, vo, 0, 0, 0);
+    }
+
+    // ---- transformed weights: step s = (ii, h, j) needs GEMM xi = (2 wx' + ii) * 4 + j, K half h, for both wx'
+    unsigned uvo[4];
+    int uwx[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int q = wave * 4 + i;                  // 0..15, uniform: wave column q >> 3, 8-row piece q & 7
+        uwx[i] = q >> 3;
+        const int row = (q & 7) * 8 + lrow;
+        uvo[i] = (unsigned)(row * 128 + ((lpos ^ ((row >> 1) & 7)) * 16));
+    }
+#define FD_UDMA(S)                                                                                \
+    do {                                                                                          \
+        const int ii_ = (S) >> 3, h_ = ((S) >> 2) & 1, j_ = (S) & 3;                              \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                           \
+            const int xi_ = (2 * uwx[i] + ii_) * 4 + j_;                                          \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(                                             \
+                ur, (__attribute__((address_space(3))) void*)(sbytes + U_OFF + ((S) & 1) * U_STAGE + (wave * 4 + i) * 1024), \
+                16, uvo[i], (xi_ * 2 + h_) * U_MAT, 0, 0);                                        \
+        }                                                                                         \
+    } while (0)
+
+    // ---- phase 1: the 16 GEMMs
+    // this lane's patch in the MFMA's row operand: block wm holds patch rows 2 wm, 2 wm + 1 (8 patches each)
+    const int pyy = wm * 2 + (frow >> 3), pxx = frow & 7;
+    const int r00 = (2 * pyy) * PW + 2 * pxx;       // patch row of the 4 x 4 input patch's top-left pixel (even)
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int g = 0; g < 8; ++g)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) acc[g][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    FD_UDMA(0);
+    wait_vmcnt<0>();
+    __syncthreads();
+
+#pragma unroll
+    for (int ii = 0; ii < 2; ++ii) {
+        // transform row i = 2 wx + ii combines input rows a1 and a2: (0, -2), (1, +2), (2, -1), (1, -3)
+        const int i_ = 2 * wx + ii;
+        const int a1 = (i_ == 0) ? 0 : (i_ == 2 ? 2 : 1);
+        const int a2 = (i_ == 0 || i_ == 1) ? 2 : (i_ == 2 ? 1 : 3);
+        const float s2 = (i_ == 1) ? 1.f : -1.f;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            // activation fragments of this (i, K half): [part][j]
+            f32x4 av[2][4];
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl) {
+                const int cq = pl * 4 + fh;
+                f32x4 rr[4];
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    const int ra = r00 + a1 * PW + b, rb = r00 + a2 * PW + b;
+                    const f32x4 d1 = *reinterpret_cast<const f32x4*>(sbytes + h * PLANE + ra * 128 + ((cq ^ ((ra >> 1) & 7)) << 4));
+                    const f32x4 d2 = *reinterpret_cast<const f32x4*>(sbytes + h * PLANE + rb * 128 + ((cq ^ ((rb >> 1) & 7)) << 4));
+                    rr[b] = d1 + s2 * d2;
+                }
+                av[pl][0] = rr[0] - rr[2];
+                av[pl][1] = rr[1] + rr[2];
+                av[pl][2] = rr[2] - rr[1];
+                av[pl][3] = rr[1] - rr[3];
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int s = ii * 8 + h * 4 + j;
+                if (s + 1 < 16) FD_UDMA(s + 1);
+                const char* ub = sbytes + U_OFF + (s & 1) * U_STAGE + wx * U_MAT;
+#pragma unroll
+                for (int pl = 0; pl < 2; ++pl) {
+                    f32x4 bv[4];
+#pragma unroll
+                    for (int ni = 0; ni < 4; ++ni)
+                        bv[ni] = *reinterpret_cast<const f32x4*>(ub + (ni * 16 + frow) * 128 + (((pl * 4 + fh) ^ sw) << 4));
+                    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                    for (int t = 0; t < 4; ++t)
+#pragma unroll
+                        for (int ni = 0; ni < 4; ++ni)
+                            acc[ii * 4 + j][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[pl][j][t], bv[ni][t], acc[ii * 4 + j][ni], 0, 0, 0);
+                    __builtin_amdgcn_s_setprio(0);
+                }
+                wait_vmcnt<0>();
+                __syncthreads();
+            }
+        }
+    }
+#undef FD_UDMA
+
+    // ---- phase 2: output transform.  T[ii][q] = the row's column combination; this wave's share of
+    // Y[p][q] = sum_i A^T[p][i] T[i][q] with A^T = (1, 1, 1, 0; 0, 1, -1, -1).  (The barrier that ended the last
+    // step separates the reads of the patch from the exchange buffer that overlays it.)
+    float* const xbuf = smem + X_OFF / 4 + wm * (4 * 4 * 4 * 64);
+    f32x4 y[4][4];          // [p * 2 + q][ni]
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) {
+        f32x4 t[2][2];
+#pragma unroll
+        for (int ii = 0; ii < 2; ++ii) {
+            t[ii][0] = acc[ii * 4 + 0][ni] + acc[ii * 4 + 1][ni] + acc[ii * 4 + 2][ni];
+            t[ii][1] = acc[ii * 4 + 1][ni] - acc[ii * 4 + 2][ni] - acc[ii * 4 + 3][ni];
+        }
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            if (wx == 0) {
+                y[0 + q][ni] = t[0][q] + t[1][q];
+                y[2 + q][ni] = t[1][q];
+            } else {
+                y[0 + q][ni] = t[0][q];
+                y[2 + q][ni] = -t[0][q] - t[1][q];
+            }
+        }
+    }
+    if (wx == 1) {
+#pragma unroll
+        for (int pq = 0; pq < 4; ++pq)
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) xbuf[((pq * 4 + ni) * 4 + r) * 64 + lane] = y[pq][ni][r];
+    }
+    __syncthreads();
+    if (wx == 0) {
+        float b2[4];
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) b2[ni] = k.bias2 ? k.bias2[ni * 16 + frow] : 0.f;
+#pragma unroll
+        for (int pq = 0; pq < 4; ++pq)
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float v = fmaxf(y[pq][ni][r] + xbuf[((pq * 4 + ni) * 4 + r) * 64 + lane] + b2[ni], 0.f);
+                    // accumulator row (lane >> 4) * 4 + r = patch of this block; column = output channel
+                    const int pm = fh * 4 + r;
+                    const int prow = (2 * (wm * 2 + (pm >> 3)) + (pq >> 1)) * 16 + 2 * (pm & 7) + (pq & 1);
+                    const int c32 = (ni & 1) * 16 + frow;
+                    *reinterpret_cast<float*>(sbytes + A_OFF + (ni >> 1) * (BM * 128) + prow * 128 +
+                                              (((c32 >> 2) ^ ((prow >> 1) & 7)) << 4) + (c32 & 3) * 4) = v;
+                }
+    }
+
+    // ---- phase 3: the 1x1 convolution, 64 output channels at a time, as conv_tail_fused_kernel's float32 form: the
+    // weight chunk shares the LDS of the epilogue staging and is fetched after the previous chunk's epilogue.
+    // Measured and not kept (1.55-1.69 ms per unit as it is): the chunk in LDS of its own with chunk ch + 1 and its
+    // residual values requested before the epilogue of chunk ch, barriers and epilogue that do not drain the
+    // vector-memory counter (1.60-1.72 ms); the residual values of all four chunks requested at once into the
+    // registers the accumulators leave (1.65-1.74 ms).  The kernel is within 1.5x of both of its floors -- 0.89 ms of
+    // matrix time, 1.04 ms of HBM time for 4.9 GB -- and what separates it from them is that a CU's two workgroups
+    // overlap their matrix and memory phases only by chance; staggering their start changed nothing.
+    const int wn = wx;
+    float* wch = smem;
+    int a3_off[MID / 32][2], b3_off[MID / 32][2];
+#pragma unroll
+    for (int kk = 0; kk < MID / 32; ++kk)
+#pragma unroll
+        for (int part = 0; part < 2; ++part) {
+            const int pos = ((part * 4 + fh) ^ sw) * 16;
+            a3_off[kk][part] = A_OFF + kk * (BM * 128) + (wm * (BM / 2) + frow) * 128 + pos;
+            b3_off[kk][part] = kk * (64 * 128) + (wn * 32 + frow) * 128 + pos;
+        }
+    constexpr int RL = E::GROUPS * E::PASSES * 2;        // residual loads per chunk and lane
+    const int nch = c.Cout / 64;
+    const PatchRows rows{(img * H + y0) * W + x0, W, min(8, H - y0), min(16, W - x0)};
+    f32x4 res[E::GROUPS][E::PASSES][2];
+    for (int ch = 0; ch < nch; ++ch) {
+        __syncthreads();               // the shared region is free: phase 2 / the previous epilogue are done with it
+#pragma unroll
+        for (int kk = 0; kk < MID / 32; ++kk)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int row = (wave + 4 * i) * 8 + lrow;
+                const unsigned vo = (unsigned)(((ch * 64 + row) * MID + kk * 32) * 4 + (lpos ^ ((row >> 1) & 7)) * 16);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(
+                    w3r, (__attribute__((address_space(3))) void*)(wch + kk * (64 * 32) + (wave + 4 * i) * 256), 16, vo, 0, 0, 0);
+            }
+        split_residual_prefetch<BM, BN>(c, rows, ch, wave, lane, res);
+        __builtin_amdgcn_sched_barrier(0);
+        wait_vmcnt<RL>();              // weights of this chunk landed; its residual may fly
+        __syncthreads();
+        f32x4 acc3[T::AM][T::AN];
+#pragma unroll
+        for (int mi = 0; mi < T::AM; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < T::AN; ++ni) acc3[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kk = 0; kk < MID / 32; ++kk) f32_mma_step<BM, BN>(sbytes, a3_off[kk], b3_off[kk], acc3);
+        // (the epilogue's own first barrier separates the last weight read from the staging writes)
+        split_epilogue16_rows<BM, BN, true>(c, smem, rows, ch, wave, lane, acc3, res);
+    }
+#endif
+}
+
+// Transformed weights of the 3x3 in the kernel's layout: U[xi][h][o][c32] = (G g G^T)[i][j] of filter (o, 32 h + c32)
+// times out_scale[o], from wino_pack_weights' [16][cout_pad][64].
+int tail_wino_pack(const float* w_oihw, const float* out_scale, std::vector<float>* packed) {
+    std::vector<float> u;
+    int cout_pad = 0;
+    FD_TRY(wino_pack_weights(w_oihw, 64, 64, out_scale, 2, &u, &cout_pad));
+    packed->assign((size_t)16 * 2 * 64 * 32, 0.f);
+    for (int xi = 0; xi < 16; ++xi)
+        for (int h = 0; h < 2; ++h)
+            for (int o = 0; o < 64; ++o)
+                for (int cc = 0; cc < 32; ++cc)
+                    (*packed)[(((size_t)xi * 2 + h) * 64 + o) * 32 + cc] = u[((size_t)xi * cout_pad + o) * 64 + h * 32 + cc];
+    return FD_OK;
+}
+
+int conv_tail_wino_forward(const float* u_wino, const float* bias2, const SplitConvParams& p3, const float* t1, int batch, int h,
+                           int w, const float* residual, const SplitConvOut& out, hipStream_t stream, bool* taken) {
+    *taken = false;
+    const ConvShape& s3 = p3.s;
+    if (!u_wino || !p3.f32 || out.b3 || !residual ||
+        !(s3.cin == 64 && s3.kh == 1 && s3.kw == 1 && s3.stride == 1 && s3.pad == 0 && s3.cout % 64 == 0))
+        return FD_OK;
+    const long long m_ll = (long long)batch * h * w;
+    const size_t x_bytes = (size_t)m_ll * 64 * 4, w3_bytes = s3.packed_floats() * 4;
+    if (x_bytes >= (1ull << 31) || m_ll >= (1ll << 29)) return FD_OK;
+    FD_REQUIRE(t1 && p3.w && (out.y32 || out.ysplit), "Winograd tail: NULL tensor");
+    TailWinoArgs k;
+    k.x = t1; k.u = u_wino; k.bias2 = bias2;
+    SplitKArgs& c = k.c;
+    c.x = nullptr; c.w = static_cast<const uint8_t*>(p3.w); c.bias = p3.bias; c.res = residual; c.y32 = out.y32;
+    c.ysplit = static_cast<uint8_t*>(out.ysplit); c.post_scale = out.post_scale; c.post_shift = out.post_shift;
+    c.pre_scale = c.pre_shift = nullptr; c.w_inv_scale = p3.w_inv_scale;
+    c.H = h; c.W = w; c.Cin = 64; c.Ho = h; c.Wo = w; c.Cout = s3.cout; c.KW = 1; c.stride = 1; c.pad = 0; c.K = 64;
+    c.M = (int)m_ll; c.relu = p3.relu; c.tiles_n = s3.cout / 64; c.ksplit = 1; c.kchunk = 2; c.partial = nullptr;
+    c.clamped = nullptr; c.f32 = 1;
+    k.H = h; k.W = w; k.tiles_x = ceil_div(w, 16); k.tiles_y = ceil_div(h, 8);
+    k.x_bytes = (unsigned)x_bytes; k.u_bytes = 16u * 2u * 64u * 32u * 4u; k.w3_bytes = (unsigned)w3_bytes;
+    // FLOPs executed: 16 GEMMs of (patches x 64 x 64) + the 1x1
+    const double patches = (double)batch * k.tiles_x * k.tiles_y * 32.0;
+    ProfScope scope(stream, "conv_tail_wino_f32", 2.0 * 16.0 * patches * 64.0 * 64.0 + 2.0 * m_ll * (double)s3.cout * 64.0,
+                    4.0 * 64.0 * m_ll + 4.0 * 64.0 * (16.0 * 64.0 + s3.cout) +
+                        4.0 * m_ll * s3.cout * (1.0 + (c.y32 ? 1.0 : 0.0) + (c.ysplit ? 1.0 : 0.0)));
+    hipLaunchKernelGGL(conv_tail_wino_kernel, dim3(batch * k.tiles_x * k.tiles_y), dim3(256), 0, stream, k);
+    FD_LAUNCH_CHECK();
+    *taken = true;
+    return FD_OK;
+}
+
+}  // namespace fd

@@ -25,6 +25,7 @@ struct Unit {
     SplitConvParams s_conv1, s_conv2, s_conv3, s_sc;   // split (f16x3) operands
     SplitConvParams f_conv1, f_conv2, f_conv3, f_sc;   // float32 operands on the same kernels
     WinoConvParams w_conv2;                            // conv2 in Winograd form (wide stride-1 layers only; both precisions)
+    const float* tailw_u = nullptr;                    // 64-channel units: conv2's F(2x2,3x3) weights for the fused float32 tail
     const float *bn1_scale = nullptr, *bn1_shift = nullptr;   // the unit's input BatchNorm (device)
     bool has_sc = false;
 };
@@ -256,6 +257,13 @@ static int build_unit(fd_detector* d, const ParamTable& t, const std::string& na
         u->w_conv2.cin = mid; u->w_conv2.cout = mid; u->w_conv2.cout_pad = cout_pad; u->w_conv2.tile = d->winograd ? d->winograd : 2;
         u->w_conv2.u = ud; u->w_conv2.bias = u->f_conv2.bias; u->w_conv2.relu = 1;
         if (mid >= 256 && d->winograd_split) FD_TRY(make_wino_split(d, uw, ud, &u->w_conv2));
+    }
+    if (stride == 1 && mid == 64) {
+        std::vector<float> uw;
+        FD_TRY(tail_wino_pack(w2->data_host, s3.data(), &uw));
+        float* ud = nullptr;
+        FD_TRY(upload(d, uw.data(), uw.size(), &ud));
+        u->tailw_u = ud;
     }
     u->has_sc = !dim_match;
     if (u->has_sc) {
@@ -583,7 +591,13 @@ static int run_unit_split(Plan& pl, const Unit& u, const char* name, const void*
                                               pl.stream));
             }
             bool fused = false;
-            if (!pl.d->layerwise())
+            // float32: the tail with its 3x3 in Winograd F(2x2,3x3) form (FD_TAIL_WINO=0, read at every call so that a
+            // test can run both: the direct-form tail below; FD_WINOGRAD=0 keeps every layer direct as well)
+            const char* tw_env = getenv("FD_TAIL_WINO");
+            const bool tail_wino = !(tw_env && atoi(tw_env) == 0);
+            if (!pl.d->layerwise() && pl.f32 && tail_wino && pl.d->winograd && u.tailw_u)
+                FD_TRY(conv_tail_wino_forward(u.tailw_u, c2.bias, c3, t1, n, h, w, res, o3, pl.stream, &fused));
+            if (!fused && !pl.d->layerwise())
                 FD_TRY(conv_tail_fused_forward(c2, c3, t1, n, h, w, res, o3, pl.stream, &fused));
             if (!fused) {
                 if (wino2) FD_TRY(wino_conv_forward(u.w_conv2, t1, n, h, w, wino_v, wino_m, t2, pl.stream, o2.b3, o2.b3_balance));

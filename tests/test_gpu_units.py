@@ -60,12 +60,18 @@ def test_fused_unit_tensors_match_elementwise(monkeypatch):
         new.close()
 
 
-def test_float32_fused_tail_matches_the_separate_float32_kernels():
-    """precision="f32": an ordinary pass runs the 3x3 + 1x1 tail of each 64-channel unit as one kernel
-    (the tensor between them stays in LDS as float32); a layer-by-layer pass runs them as two.  Same
-    float32 products, and the 1x1 sums its 64 terms in the same order, so unit outputs agree to
-    rounding noise of the 3x3's different summation order."""
+@pytest.mark.parametrize("tail", ["winograd", "direct"])
+def test_float32_fused_tail_matches_the_separate_float32_kernels(monkeypatch, tail):
+    """precision="f32": an ordinary pass runs the 3x3 + 1x1 tail of each 64-channel unit as one kernel (the tensor
+    between them stays in LDS as float32) -- with the 3x3 in Winograd F(2x2,3x3) form (fd_conv_tailw.hip: transforms
+    in registers, nothing of the Winograd domain in memory; the default) or, with FD_TAIL_WINO=0, as a direct
+    convolution (conv_tail_fused_kernel); a layer-by-layer pass runs two direct kernels.  Same float32 products up to
+    the order of summation (and, for the Winograd form, its additions-only transforms), so unit outputs agree to
+    rounding noise.  The frame sizes give stage-1 maps smaller than one 8 x 16 tile, ragged in both directions, and
+    many tiles large."""
+    from facedetection_amd import profiling
     from facedetection_amd.detection import Detector
+    monkeypatch.setenv("FD_TAIL_WINO", "1" if tail == "winograd" else "0")
     lay = Detector("synthetic:0", 0, own_context=True, precision="f32")
     new = Detector("synthetic:0", 0, own_context=True, precision="f32")
     lay.keep_tensors(True)
@@ -75,7 +81,10 @@ def test_float32_fused_tail_matches_the_separate_float32_kernels():
         for (b, h, w) in SIZES:
             frames = rng.integers(0, 256, size=(b, h, w, 3), dtype=np.uint8)
             lay.forward(frames)
+            profiling.begin()
             new.forward(frames)
+            ran = {r["kernel"] for r in profiling.end()}
+            assert ("conv_tail_wino_f32" in ran) == (tail == "winograd") and ("conv_tail_fused_f32" in ran) == (tail == "direct"), ran
             for name in ("stage1_unit1", "stage1_unit2", "stage1_unit3"):
                 want, got = lay.tensor(name), new.tensor(name)
                 assert want.shape == got.shape

@@ -70,7 +70,7 @@ def main():
     path = sys.argv[1]
     B = int(sys.argv[2]) if len(sys.argv) > 2 else 8
     rows = [r for r in csv.DictReader(open(path))
-            if any(t in r["Kernel_Name"] for t in ("conv_igemm", "conv_split_", "stem_pool", "conv_tail_fused", "unit_fused", "unit_proj_fused", "conv_f32_panel"))]
+            if any(t in r["Kernel_Name"] for t in ("conv_igemm", "conv_split_", "stem_pool", "conv_tail_fused", "unit_fused", "unit_proj_fused", "conv_f32_panel", "conv_tail_wino"))]
     layers = layer_list(B, mode=sys.argv[3] if len(sys.argv) > 3 else "f16x3", tile=int(sys.argv[4]) if len(sys.argv) > 4 else 4)
     last = rows[-len(layers):]
     tot = totf = 0.0
