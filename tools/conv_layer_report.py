@@ -60,8 +60,14 @@ def layer_list(B, H=1080, W=1920, R=10, mode="f16x3", tile=4):
                 # f16x3: whole unit in one kernel (4 layers for the projection unit); f32: conv2 + conv3
                 k = 2 if mode == "f32" else (4 if u == 0 else 3)
                 parts = [layers.pop() for _ in range(k)]
+                flops = sum(p[4] for p in parts)
+                if mode == "f32":
+                    # the tail's 3x3 runs as Winograd F(2x2,3x3) inside the kernel: 16 GEMMs over the 2 x 2 patches of
+                    # whole 8 x 16 pixel tiles, plus the 1x1 (FLOPs executed, like the other rows)
+                    patches = n * ((h + 7) // 8) * ((w + 15) // 16) * 32
+                    flops = 2.0 * 16 * patches * mid * mid + 2.0 * n * h2 * w2 * mid * cout
                 layers.append((nm + ("_tail" if mode == "f32" else "_unit"), parts[0][1], parts[0][2],
-                               sum(p[3] for p in parts), sum(p[4] for p in parts)))
+                               sum(p[3] for p in parts), flops))
             h, w, cin = h2, w2, cout
     return layers
 
