@@ -6,7 +6,7 @@ set -e
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 TMP=$(mktemp -d)
 python3 -m facedetection_amd._build > /dev/null      # writes the build-id header fd_core.hip includes
-for f in fd_core fd_boxes fd_image fd_conv fd_conv_split fd_conv_fused fd_winograd fd_detector; do
+for f in fd_core fd_boxes fd_image fd_conv fd_conv_split fd_conv_panel fd_conv_tailw fd_conv_fused fd_winograd fd_detector; do
     extra=""
     case $f in fd_boxes|fd_image) extra="-ffp-contract=off";; esac
     /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 $extra -I $ROOT/facedetection_amd/csrc/build --cuda-device-only \
