@@ -10,9 +10,14 @@
 //     (80 KB of LDS per workgroup: two workgroups per CU, each covering the other's prologue);
 //   * the eight waves form two groups of four that alternate: while one group runs the MFMAs of chunk
 //     c out of LDS, the other writes out chunk c - 1 (transpose through the ring buffer chunk c - 1 has
-//     just released, residual add, stores), requests the weights of chunk c + 1 and the residual values
-//     it will need next.  Every SIMD hosts one wave of each group, so its matrix pipe always has a wave
-//     in its MFMA phase, and the memory traffic of the epilogues is spread evenly under the MFMAs.
+//     just released, residual add, stores) and requests the weights of chunk c + 1.  A chunk's residual
+//     values are requested when its MFMA phase begins, a whole phase before they are added, and the
+//     stores of an epilogue stay in flight into the next phases.  Every SIMD hosts a wave of each group
+//     of both resident workgroups, so its matrix pipe always has a wave in its MFMA phase, and the
+//     memory traffic of the epilogues is spread evenly under the MFMAs.  (A workgroup that alternates
+//     between a matrix phase and a memory phase of about equal length is one customer of two stations;
+//     with N of them per CU the kernel runs at about N / (N + 1) of its floor.  The two groups make a
+//     workgroup two customers: four per CU here, against three of the general kernel's 128 x 64 tile.)
 // Operand images in LDS, fragment addressing, the order in which an output element accumulates over K
 // and the arithmetic of the epilogue are those of conv_split_glds_kernel<.., F32>: results are
 // bit-identical to that kernel's.
