@@ -37,6 +37,14 @@ int pack_conv_weights_split(const float* w_oihw, int cin_w, const ConvShape& s, 
 int split_conv_forward(const SplitConvParams& p, const void* x_split, int batch, int h, int w, const float* residual,
                        const SplitConvOut& out, hipStream_t stream);
 
+// Two 1x1 / stride-1 float32 convolutions of the same input in one launch (a projection unit's shortcut and its first
+// convolution): w_pair = pa's packed weight rows (pa.s.cout of them, a multiple of 64) followed by 64 rows of pb's
+// (pb.s.cout <= 64 real rows, the rest zero).  ya [M][pa.s.cout] gets pa's result (pa.bias / pa.relu), yb [M][pb.s.cout]
+// pb's (pb.bias / pb.relu).  Same accumulation order and epilogue as two split_conv_forward calls: the same bits.
+// *taken is false (and nothing is launched) when the shapes are not the ones this form is for.
+int split_conv_forward_pair(const SplitConvParams& pa, const SplitConvParams& pb, const float* w_pair, size_t w_pair_floats,
+                            const float* x, int batch, int h, int w, float* ya, float* yb, hipStream_t stream, bool* taken);
+
 // The same convolution on a float32 input [B][H][W][cin] that enters as
 // split(relu(x * pre_scale[c] + pre_shift[c])), converted while the tile is staged.
 int split_conv_forward_f32(const SplitConvParams& p, const float* x32, const float* pre_scale, const float* pre_shift,

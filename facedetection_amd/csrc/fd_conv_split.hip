@@ -499,6 +499,18 @@ __global__ __launch_bounds__(WAVES * 64, OCC ? OCC : (WAVES == 4 ? 2 : 1)) void 
         e.y32 = a.partial + (size_t)ks * a.M * a.Cout;
         e.ysplit = nullptr; e.bias = nullptr; e.res = nullptr; e.relu = 0;
         split_epilogue16_rows<2 * WROWS, BN, false>(e, smem, LinearRows{tile_m * BM, a.M}, tile_n, wave, lane, acc);
+    } else if (a.alt_y) {
+        // two layers in one launch: this tile's columns belong to the first (row length alt_from) or the second
+        SplitKArgs e = a;
+        int tn = tile_n;
+        if (tile_n * BN >= a.alt_from) {
+            tn = tile_n - a.alt_from / BN;
+            e.Cout = a.alt_cout; e.y32 = nullptr; e.ysplit = a.alt_y; e.bias = a.alt_bias; e.relu = a.alt_relu;
+            e.res = nullptr; e.post_scale = nullptr; e.post_shift = nullptr;
+        } else {
+            e.Cout = a.alt_from;
+        }
+        split_epilogue16_rows<2 * WROWS, BN, false>(e, smem, LinearRows{tile_m * BM, a.M}, tn, wave, lane, acc);
     } else {
         split_epilogue16_rows<2 * WROWS, BN, false>(a, smem, LinearRows{tile_m * BM, a.M}, tile_n, wave, lane, acc);
     }
@@ -1085,6 +1097,34 @@ int gemm_split_batched(const void* a_split, const void* w_split, unsigned w_set_
     // (256 x 128 and 128 x 128 tiles measured the same on the K = 256 GEMMs of the 256-channel stage)
     if (cout >= 256) return launch_split_glds<256, 256, 2, 8>(a, x_bytes, w_bytes, stream);
     return launch_split_glds<256, 128, 3, 8>(a, x_bytes, w_bytes, stream);
+}
+
+int split_conv_forward_pair(const SplitConvParams& pa, const SplitConvParams& pb, const float* w_pair, size_t w_pair_floats,
+                            const float* x, int batch, int h, int w, float* ya, float* yb, hipStream_t stream, bool* taken) {
+    *taken = false;
+    const ConvShape &sa = pa.s, &sb = pb.s;
+    // FD_F32_PAIR=0: two launches (read at every call so that a test can compare the two forms in one process)
+    const char* env = getenv("FD_F32_PAIR");
+    if ((env && atoi(env) == 0) || !pa.f32 || !pb.f32 || !w_pair || sa.cin != sb.cin || sa.cin % 32 != 0 || sa.kh != 1 || sa.kw != 1 ||
+        sb.kh != 1 || sb.kw != 1 || sa.stride != 1 || sb.stride != 1 || sa.pad != 0 || sb.pad != 0 || sa.cout % 64 != 0 ||
+        sb.cout % 32 != 0 || sb.cout > 64)
+        return FD_OK;
+    const long long m_ll = (long long)batch * h * w;
+    const size_t x_bytes = (size_t)m_ll * sa.cin * 4, w_bytes = w_pair_floats * 4;
+    if (x_bytes >= (1ull << 31) || w_bytes >= (1ull << 31) || m_ll >= (1ll << 29) || ceil_div(m_ll, 128) < 768) return FD_OK;
+    FD_REQUIRE(x && ya && yb, "paired convolution: NULL tensor");
+    SplitKArgs a;
+    a.x = reinterpret_cast<const uint8_t*>(x);
+    a.w = reinterpret_cast<const uint8_t*>(w_pair);
+    a.bias = pa.bias; a.res = nullptr; a.y32 = ya; a.ysplit = nullptr; a.post_scale = a.post_shift = nullptr;
+    a.pre_scale = a.pre_shift = nullptr; a.w_inv_scale = 1.f;
+    a.H = h; a.W = w; a.Cin = sa.cin; a.Ho = h; a.Wo = w; a.Cout = sa.cout + 64; a.KW = 1; a.stride = 1; a.pad = 0;
+    a.K = sa.cin; a.M = (int)m_ll; a.relu = pa.relu; a.tiles_n = 0; a.ksplit = 1; a.kchunk = a.K / SBK; a.partial = nullptr;
+    a.clamped = nullptr; a.f32 = 1;
+    a.alt_from = sa.cout; a.alt_y = reinterpret_cast<uint8_t*>(yb); a.alt_cout = sb.cout; a.alt_bias = pb.bias;
+    a.alt_relu = pb.relu;
+    *taken = true;
+    return launch_split_glds<128, 64, 2, 4, true, 3>(a, x_bytes, w_bytes, stream);
 }
 
 int split_conv_forward(const SplitConvParams& p, const void* x_split, int batch, int h, int w, const float* residual,

@@ -32,6 +32,15 @@ struct SplitKArgs {
     unsigned wbatch_bytes = 0;
     int b3_balance = 63;     // bf16x3: percentage of a tile's K-steps accumulated as +(sum); the rest as -(sum), which
                              // cancels the matrix unit's rounding bias (0: everything as +(sum))
+    // two convolutions of the same input in one launch (direct-to-LDS kernel only): the weight rows from alt_from on
+    // (a multiple of the tile width) belong to a second layer with its own output tensor [M][alt_cout] (written
+    // like `ysplit`: float32 in float32 mode), bias and ReLU flag; columns below alt_from form the first layer, whose
+    // output row length is alt_from
+    int alt_from = 0;
+    uint8_t* alt_y = nullptr;
+    int alt_cout = 0;
+    const float* alt_bias = nullptr;
+    int alt_relu = 0;
     int stream_res = 0;      // residual values of large tensors are read with streaming loads
     int f32;                 // float32 operands (1; 2: with bf16x3 products): x, w and the "split" output are plain float32 tensors (same
                              // 4 bytes per element, so the same addressing; 128-byte rows of 32 floats)

@@ -26,6 +26,8 @@ struct Unit {
     SplitConvParams f_conv1, f_conv2, f_conv3, f_sc;   // float32 operands on the same kernels
     WinoConvParams w_conv2;                            // conv2 in Winograd form (wide stride-1 layers only; both precisions)
     const float* tailw_u = nullptr;                    // 64-channel units: conv2's F(2x2,3x3) weights for the fused float32 tail
+    const float* pair_w = nullptr;                     // stride-1 projection units: shortcut rows + conv1 rows, one float32 GEMM
+    size_t pair_w_floats = 0;
     const float *bn1_scale = nullptr, *bn1_shift = nullptr;   // the unit's input BatchNorm (device)
     bool has_sc = false;
 };
@@ -272,6 +274,18 @@ static int build_unit(fd_detector* d, const ParamTable& t, const std::string& na
         FD_TRY(make_conv(d, ws->data_host, cin, shape(cin, cout, 1, stride, 0), nullptr, nullptr, 0, &u->sc, &u->s_sc, &u->f_sc));
         u->sc.pre_scale = pre_s;
         u->sc.pre_shift = pre_h;
+        if (stride == 1 && mid <= 64 && cout % 64 == 0 && u->f_sc.w && u->f_conv1.w) {
+            // the shortcut and conv1 read the same tensor: their float32 weight rows in one buffer, conv1's padded to 64
+            const size_t k = (size_t)cin;
+            float* pw = nullptr;
+            FD_HIP(hipMalloc((void**)&pw, ((size_t)cout + 64) * k * sizeof(float)));
+            d->owned.push_back(pw);
+            FD_HIP(hipMemset(pw, 0, ((size_t)cout + 64) * k * sizeof(float)));
+            FD_HIP(hipMemcpy(pw, u->f_sc.w, (size_t)cout * k * sizeof(float), hipMemcpyDeviceToDevice));
+            FD_HIP(hipMemcpy(pw + (size_t)cout * k, u->f_conv1.w, (size_t)mid * k * sizeof(float), hipMemcpyDeviceToDevice));
+            u->pair_w = pw;
+            u->pair_w_floats = ((size_t)cout + 64) * k;
+        }
     }
     return FD_OK;
 }
@@ -560,12 +574,19 @@ static int run_unit_split(Plan& pl, const Unit& u, const char* name, const void*
     if (u.has_sc && !pl.dry && (!pl.d->layerwise() || (pl.d->fuse_units & 4)) && (pl.d->fuse_units & 2) && y32 && !ysplit)
         FD_TRY(unit_proj_fused_forward(c1, c2, c3, csc, act, n, h, w, y32, pl.d->clamped,
                                        pl.stream, &whole_proj));
+    bool pair_done = false;
     if (u.has_sc) {
         float* s = pl.buf(NB_SC, (size_t)n * ho * wo * cout);
         if (!pl.dry && !whole_proj) {
-            SplitConvOut o = pl.out();
-            o.y32 = s;
-            FD_TRY(split_conv_forward(csc, act, n, h, w, nullptr, o, pl.stream));
+            // float32, stride 1: the shortcut and conv1 as one launch (both read act)
+            if (pl.f32 && pl.d->precision == FD_PRECISION_F32 && !pl.d->layerwise() && u.pair_w)
+                FD_TRY(split_conv_forward_pair(csc, c1, u.pair_w, u.pair_w_floats, static_cast<const float*>(act), n, h, w, s, t1,
+                                               pl.stream, &pair_done));
+            if (!pair_done) {
+                SplitConvOut o = pl.out();
+                o.y32 = s;
+                FD_TRY(split_conv_forward(csc, act, n, h, w, nullptr, o, pl.stream));
+            }
         }
         res = s;
     }
@@ -585,7 +606,7 @@ static int run_unit_split(Plan& pl, const Unit& u, const char* name, const void*
                                       pl.stream, &whole));
         if (!whole) {
             if (u.has_sc) {
-                FD_TRY(split_conv_forward(c1, act, n, h, w, nullptr, o1, pl.stream));
+                if (!pair_done) FD_TRY(split_conv_forward(c1, act, n, h, w, nullptr, o1, pl.stream));
             } else {
                 FD_TRY(split_conv_forward_f32(c1, xraw, u.bn1_scale, u.bn1_shift, n, h, w, nullptr, o1,
                                               pl.stream));

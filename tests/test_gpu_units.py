@@ -93,3 +93,31 @@ def test_float32_fused_tail_matches_the_separate_float32_kernels(monkeypatch, ta
     finally:
         lay.close()
         new.close()
+
+
+def test_paired_shortcut_and_conv1_launch_gives_the_same_bits(monkeypatch):
+    """precision="f32": the first unit of the 64-channel stage runs its shortcut convolution and its conv1 -- both 1x1,
+    stride 1, same input -- as ONE launch of the direct-to-LDS kernel (weight rows concatenated, two output tensors;
+    faster_rcnn.py:33,51).  Every output element accumulates and is finished exactly as in two launches
+    (FD_F32_PAIR=0), so the unit's output is the same bit for bit."""
+    from facedetection_amd import profiling
+    from facedetection_amd.detection import Detector
+    det = Detector("synthetic:0", 0, own_context=True, precision="f32")
+    det.keep_tensors(True, production=True)
+    rng = np.random.default_rng(5)
+    try:
+        for (b, h, w) in [(2, 1080, 1920), (3, 1000, 1500)]:      # (the form is taken from 768 row tiles on)
+            frames = rng.integers(0, 256, size=(b, h, w, 3), dtype=np.uint8)
+            got, launches = {}, {}
+            for pair in ("1", "0"):
+                monkeypatch.setenv("FD_F32_PAIR", pair)
+                profiling.begin()
+                det.forward(frames)
+                rows = {r["kernel"]: r["launches"] for r in profiling.end()}
+                launches[pair] = sum(n for k, n in rows.items() if k.startswith("conv_"))
+                got[pair] = {name: det.tensor(name).copy() for name in ("stage1_unit1", "stage1_unit3", "feat")}
+            assert launches["0"] == launches["1"] + 1, launches          # one convolution launch fewer
+            for name in got["1"]:
+                assert np.array_equal(got["1"][name], got["0"][name]), (name, (b, h, w))
+    finally:
+        det.close()

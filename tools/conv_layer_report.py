@@ -68,6 +68,12 @@ def layer_list(B, H=1080, W=1920, R=10, mode="f16x3", tile=4):
                     flops = 2.0 * 16 * patches * mid * mid + 2.0 * n * h2 * w2 * mid * cout
                 layers.append((nm + ("_tail" if mode == "f32" else "_unit"), parts[0][1], parts[0][2],
                                sum(p[3] for p in parts), flops))
+                if mode == "f32" and u == 0:
+                    # float32: the stride-1 projection unit's shortcut and conv1 (same input) are one launch
+                    tail_row = layers.pop()
+                    c1_row, sc_row = layers.pop(), layers.pop()
+                    layers.append((nm + "_sc+c1", sc_row[1], sc_row[2] + c1_row[2], sc_row[3], sc_row[4] + c1_row[4]))
+                    layers.append(tail_row)
             h, w, cin = h2, w2, cout
     return layers
 
@@ -85,7 +91,7 @@ def main():
         us = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
         tot += us
         totf += L[4]
-        kind = L[0].split("_")[-1] if "_" in L[0] else L[0]
+        kind = L[0].split("_")[-1].split("+")[0] if "_" in L[0] else L[0]
         g = groups.setdefault(kind, [0.0, 0.0])
         g[0] += us
         g[1] += L[4]
