@@ -97,9 +97,9 @@ def test_float32_fused_tail_matches_the_separate_float32_kernels(monkeypatch, ta
 
 def test_paired_shortcut_and_conv1_launch_gives_the_same_bits(monkeypatch):
     """precision="f32": the first unit of the 64-channel stage runs its shortcut convolution and its conv1 -- both 1x1,
-    stride 1, same input -- as ONE launch of the direct-to-LDS kernel (weight rows concatenated, two output tensors;
-    faster_rcnn.py:33,51).  Every output element accumulates and is finished exactly as in two launches
-    (FD_F32_PAIR=0), so the unit's output is the same bit for bit."""
+    stride 1, same input -- as ONE launch of the direct-to-LDS kernel when FD_F32_PAIR=1 (weight rows concatenated, two
+    output tensors; faster_rcnn.py:33,51; off by default).  Every output element accumulates and is finished exactly as
+    in two launches, so the unit's output is the same bit for bit."""
     from facedetection_amd import profiling
     from facedetection_amd.detection import Detector
     det = Detector("synthetic:0", 0, own_context=True, precision="f32")

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Per-layer convolution timing from a rocprofv3 kernel trace of bench.py.
 
-    python tools/conv_layer_report.py <kernel_trace.csv> [micro_batch] [f16x3 | f32 | layers] [winograd tile: 4 | 2]
+    python tools/conv_layer_report.py <kernel_trace.csv> [micro_batch] [f16x3 | f32 | f32pair | layers] [winograd tile: 4 | 2]
+                                                        (f32pair: a float32 trace taken with FD_F32_PAIR=1)
 
 Takes the convolution launches of the last complete forward pass in the trace, pairs them with
 the launch list of faster_rcnn50 at 1080p (same order as the library issues them, see layer_list)
@@ -19,7 +20,11 @@ def layer_list(B, H=1080, W=1920, R=10, mode="f16x3", tile=4):
     mode "f32": fused stem, the 3x3 + 1x1 tail of each 64-channel unit is one kernel, and the stride-1 3x3
     layers from 128 channels on (256 with tile 2) and the RPN's are one batched Winograd GEMM launch each
     ((tile + 2)^2 GEMMs over the tile x tile patches: 1/4 of the direct FLOPs with tile 4, 4/9 with tile 2,
-    rows padded to whole GEMM tiles); mode "layers": every layer its own launch."""
+    rows padded to whole GEMM tiles); mode "f32pair": "f32" with the stride-1 projection unit's shortcut and conv1 as
+    one launch (FD_F32_PAIR=1); mode "layers": every layer its own launch."""
+    pair = mode == "f32pair"
+    if pair:
+        mode = "f32"
     layers = []
 
     def conv(name, n, h, w, cin, cout, k, s, p, wino=False):
@@ -68,8 +73,8 @@ def layer_list(B, H=1080, W=1920, R=10, mode="f16x3", tile=4):
                     flops = 2.0 * 16 * patches * mid * mid + 2.0 * n * h2 * w2 * mid * cout
                 layers.append((nm + ("_tail" if mode == "f32" else "_unit"), parts[0][1], parts[0][2],
                                sum(p[3] for p in parts), flops))
-                if mode == "f32" and u == 0:
-                    # float32: the stride-1 projection unit's shortcut and conv1 (same input) are one launch
+                if pair and u == 0:
+                    # the stride-1 projection unit's shortcut and conv1 (same input) as one launch
                     tail_row = layers.pop()
                     c1_row, sc_row = layers.pop(), layers.pop()
                     layers.append((nm + "_sc+c1", sc_row[1], sc_row[2] + c1_row[2], sc_row[3], sc_row[4] + c1_row[4]))
