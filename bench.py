@@ -105,7 +105,7 @@ def pmc_traffic(kernel):
     import re
     from facedetection_amd import _lib
     build = _lib.lib().fd_build_id().decode("ascii")
-    m = re.match(r"conv_(split|f32|igemm)_(\d+)x(\d+)(_pre|_o\d)?$", kernel)
+    m = re.match(r"conv_(split|f32|igemm)_(\d+)x(\d+)(_pre|_o\d)?(_bn)?$", kernel)
     # (the passes over the front-end benchmark, *_frontend_pmc_traffic.json, do not cover this benchmark's kernels)
     files = sorted(f for f in glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic.json"))
                    if "frontend" not in os.path.basename(f))
@@ -121,6 +121,8 @@ def pmc_traffic(kernel):
     occ = m.group(4)[2:] if (m.group(4) or "").startswith("_o") else "0"    # workgroups per CU asked for (0: default)
     if family == "igemm":
         want = re.compile(r"conv_igemm_kernel<%s, %s, false>" % (bm, bn))
+    elif m.group(5):   # direct-to-LDS kernel with BatchNorm on the fragments: <BM, BN, stages, workgroups per CU, channels kept>
+        want = re.compile(r"conv_split_glds_pre_kernel<%s, %s, \d+, %s, \d+>" % (bm, bn, occ))
     elif pre:       # BatchNorm-on-load kernel: <BM, BN, mode 0, float32 operands?>
         want = re.compile(r"conv_split_reg_kernel<%s, %s, 0, %s(, false)?>" % (bm, bn, "true" if family == "f32" else "false"))
     else:           # direct-to-LDS kernel: <BM, BN, stages, waves, float32 operands?, workgroups per CU, bf16x3 products?>

@@ -501,19 +501,19 @@ static int conv2d_f32_operands(fd_ctx* ctx, const float* x_nhwc, int batch, int 
     FD_TRY(fd::scratch_as(ctx, fd::SLOT_MISC0, p.s.packed_floats(), &packed));
     FD_TRY(fd::pack_conv_weights(w_oihw, cin, p.s, nullptr, packed, fd::as_stream(stream)));
     p.w = packed; p.bias = bias; p.pre_scale = pre_scale; p.pre_shift = pre_shift; p.relu = relu;
-    // Layers without an input BatchNorm take the direct-to-LDS kernel, like the detector's float32 pass
-    // (FD_F32_GLDS=0 keeps the register-staged kernel for comparisons).
+    // The kernels of the detector's float32 pass (FD_F32_GLDS=0 keeps the older register-staged kernel for
+    // comparisons).
     static const bool glds = !(getenv("FD_F32_GLDS") && atoi(getenv("FD_F32_GLDS")) == 0);
     const size_t x_bytes = (size_t)batch * height * width * cin * 4;
     const bool reach = x_bytes < (1ull << 31) && p.s.packed_floats() * 4 < (1ull << 31) && cout % 8 == 0;
     FD_REQUIRE(!b3 || reach, "fd_conv2d_bf16x3: tensor beyond the 2^31-byte reach of the buffer-addressed kernels");
-    if ((glds || b3) && reach && (!pre_scale || b3)) {
+    if ((glds || b3) && reach) {
         fd::SplitConvParams sp;
         sp.s = p.s; sp.w = packed; sp.w_inv_scale = 1.f; sp.bias = bias; sp.relu = relu; sp.f32 = true;
         fd::SplitConvOut o;
         o.y32 = y_nhwc;
         o.b3 = b3;
-        if (pre_scale)     // BatchNorm + ReLU on load: the register-staged kernel
+        if (pre_scale)     // BatchNorm + ReLU on load: the detector's kernels for the first convolution of a unit
             return fd::split_conv_forward_f32(sp, x_nhwc, pre_scale, pre_shift, batch, height, width, residual, o,
                                               fd::as_stream(stream));
         return fd::split_conv_forward(sp, x_nhwc, batch, height, width, residual, o, fd::as_stream(stream));

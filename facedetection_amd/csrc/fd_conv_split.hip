@@ -302,10 +302,15 @@ __global__ __launch_bounds__(256, 2) void conv_split_kernel(SplitKArgs a) {
 // against 3e-10 for the float32 unit, at equal rms error), a bias that survives averaging layers.  The second half of
 // a tile's K-steps is therefore accumulated as -(sum): the accumulators change sign at the midpoint and at the end and
 // the activation operand enters negated in between, so the two halves' biases cancel.
-template <int BM, int BN, int NS, int WAVES = 4, bool F32 = false, int OCC = 0, bool B3 = false>
-__global__ __launch_bounds__(WAVES * 64, OCC ? OCC : (WAVES == 4 ? 2 : 1)) void conv_split_glds_kernel(SplitKArgs a, unsigned x_bytes,
-                                                                                      unsigned w_bytes) {
+// PREK > 0 (float32, 1x1 layers of at most PREK input channels): the input is the unit's raw float32 tensor and
+// BatchNorm + ReLU are applied to the activation fragments in registers, between their LDS reads and the MFMAs
+// (scale and shift of all K channels sit in LDS behind the pipeline stages); the loads stay direct-to-LDS with
+// counted waits, where the register-staged kernel below drains its loads at every K-step.  The activated values and
+// the order of the products are those of the register-staged kernel, so both give the same bits.
+template <int BM, int BN, int NS, int WAVES, bool F32, int OCC, bool B3, int PREK>
+__device__ __forceinline__ void conv_split_glds_body(const SplitKArgs& a, unsigned x_bytes, unsigned w_bytes) {
     static_assert(!B3 || F32, "bf16x3 products are formed from float32 operand images");
+    static_assert(PREK == 0 || (F32 && !B3 && PREK % 32 == 0), "BatchNorm on the fragments: float32 products only");
 #if defined(__HIP_DEVICE_COMPILE__)   // buffer-resource builtins exist in device code only; the host pass needs just the stub
     constexpr int WROWS = BM / (WAVES / 2);     // rows of the tile per wave row
     using T = SplitTile<2 * WROWS, BN>;         // per-wave geometry: that of a 2 x 2 grid over 2 WROWS rows
@@ -316,7 +321,8 @@ __global__ __launch_bounds__(WAVES * 64, OCC ? OCC : (WAVES == 4 ? 2 : 1)) void 
     constexpr int SMEM = (NS * STAGE > EPI) ? NS * STAGE : EPI;
     static_assert(BM % (8 * WAVES) == 0 && BN % (8 * WAVES) == 0 && WROWS % 32 == 0 && SMEM * 4 <= 160 * 1024, "tile shape");
     static_assert(NS >= 2 && NS <= 4 && (NS - 2) * PIECES < 64, "pipeline depth");
-    __shared__ __attribute__((aligned(16))) float smem[SMEM];
+    static_assert((SMEM + 2 * PREK) * 4 <= 160 * 1024, "LDS");
+    __shared__ __attribute__((aligned(16))) float smem[SMEM + 2 * PREK];
 
     // the wave index is uniform: keeping it in a scalar register makes every LDS destination
     // address of the loads below scalar arithmetic
@@ -330,6 +336,15 @@ __global__ __launch_bounds__(WAVES * 64, OCC ? OCC : (WAVES == 4 ? 2 : 1)) void 
     }
     const int ks = wgid % a.ksplit;
     const int tile_n = (wgid / a.ksplit) % a.tiles_n, tile_m = wgid / (a.ksplit * a.tiles_n);
+
+    if constexpr (PREK > 0) {
+        // scale | shift of every input channel (before any LDS-DMA is issued: these are ordinary loads, and the
+        // first barrier of the pipeline below publishes them)
+        for (int i = tid * 4; i < a.K; i += WAVES * 256) {
+            *reinterpret_cast<f32x4*>(smem + SMEM + i) = *reinterpret_cast<const f32x4*>(a.pre_scale + i);
+            *reinterpret_cast<f32x4*>(smem + SMEM + PREK + i) = *reinterpret_cast<const f32x4*>(a.pre_shift + i);
+        }
+    }
 
     const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, x_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, w_bytes, 0x00020000);
@@ -452,6 +467,9 @@ __global__ __launch_bounds__(WAVES * 64, OCC ? OCC : (WAVES == 4 ? 2 : 1)) void 
         b_off[part] = (BM + wn * (BN / 2) + frow) * 128 + pos;
     }
 
+    // BatchNorm on the fragments: this lane's scale values of K-step 0, part 0 (the shifts sit PREK floats on)
+    const char* pre_base = sbase + (SMEM + fh * 4) * 4;
+
     // bf16x3: K-steps from `half` on are accumulated negated
     const int half = (B3 && a.b3_balance > 0 && nk > 1) ? max(1, min(nk - 1, (nk * a.b3_balance + 50) / 100)) : nk + 1;
     unsigned flip = 0u;
@@ -466,6 +484,9 @@ __global__ __launch_bounds__(WAVES * 64, OCC ? OCC : (WAVES == 4 ? 2 : 1)) void 
         if (B3) {                                                                                 \
             if ((KT) == half) { FD_NEGATE(); flip = 0x80000000u; }                                \
             bf16x3_mma_step<2 * WROWS, BN>(sbase + (CUR) * STAGE * 4, a_off, b_off, acc, flip);   \
+        } else if (PREK > 0) {                                                                    \
+            f32_mma_step_pre<2 * WROWS, BN>(sbase + (CUR) * STAGE * 4, a_off, b_off, acc,         \
+                                            pre_base + (kb + (KT)) * 128, PREK * 4);              \
         } else if (F32) f32_mma_step<2 * WROWS, BN>(sbase + (CUR) * STAGE * 4, a_off, b_off, acc); \
         else split_mma_step<2 * WROWS, BN>(sbase + (CUR) * STAGE * 4, a_off, b_off, acc);         \
         FD_WAIT(min(NS - 2, nk - 2 - (KT)));                                                      \
@@ -515,6 +536,36 @@ __global__ __launch_bounds__(WAVES * 64, OCC ? OCC : (WAVES == 4 ? 2 : 1)) void 
         split_epilogue16_rows<2 * WROWS, BN, false>(a, smem, LinearRows{tile_m * BM, a.M}, tile_n, wave, lane, acc);
     }
 #endif
+}
+
+template <int BM, int BN, int NS, int WAVES = 4, bool F32 = false, int OCC = 0, bool B3 = false>
+__global__ __launch_bounds__(WAVES * 64, OCC ? OCC : (WAVES == 4 ? 2 : 1)) void conv_split_glds_kernel(SplitKArgs a, unsigned x_bytes,
+                                                                                      unsigned w_bytes) {
+    conv_split_glds_body<BM, BN, NS, WAVES, F32, OCC, B3, 0>(a, x_bytes, w_bytes);
+}
+
+// float32, BatchNorm + ReLU on the activation fragments (input channels <= PREK)
+template <int BM, int BN, int NS, int OCC, int PREK>
+__global__ __launch_bounds__(256, OCC ? OCC : 2) void conv_split_glds_pre_kernel(SplitKArgs a, unsigned x_bytes, unsigned w_bytes) {
+    conv_split_glds_body<BM, BN, NS, 4, true, OCC, false, PREK>(a, x_bytes, w_bytes);
+}
+
+template <int BM, int BN, int NS, int OCC, int PREK>
+static int launch_split_glds_pre(const SplitKArgs& a, size_t x_bytes, size_t w_bytes, hipStream_t stream) {
+    static const std::string name = std::string("conv_f32_") + std::to_string(BM) + "x" + std::to_string(BN) +
+                                    (OCC ? "_o" + std::to_string(OCC) : std::string()) + "_bn";
+    FD_REQUIRE(a.f32 == 1 && a.pre_scale && a.pre_shift && a.K == a.Cin && a.pad == 0 && a.stride == 1 && a.K <= PREK && !a.alt_y,
+               "conv_split_glds_pre: not a 1x1 float32 layer of at most %d channels", PREK);
+    ProfScope scope(stream, name.c_str(), 2.0 * a.M * a.Cout * (double)a.K,
+                    4.0 * a.M * a.Cin + 4.0 * a.Cout * (double)a.K +
+                        4.0 * a.M * a.Cout * ((a.res ? 1.0 : 0.0) + (a.y32 ? 1.0 : 0.0) + (a.ysplit ? 1.0 : 0.0)));
+    SplitKArgs k = a;
+    const int tiles_m = ceil_div(a.M, BM);
+    k.tiles_n = ceil_div(a.Cout, BN);
+    hipLaunchKernelGGL((conv_split_glds_pre_kernel<BM, BN, NS, OCC, PREK>), dim3(tiles_m * k.tiles_n * k.ksplit), dim3(256), 0,
+                       stream, k, (unsigned)x_bytes, (unsigned)w_bytes);
+    FD_LAUNCH_CHECK();
+    return FD_OK;
 }
 
 template <int BM, int BN, int NS, int WAVES = 4, bool F32 = false, int OCC = 0, bool B3 = false>
@@ -934,7 +985,11 @@ static int split_conv_dispatch(const SplitConvParams& p, const void* x_split, co
         a.ksplit = choose_split_k(ho * wo, a.K / SBK, (long long)a.M * s.cout, out.splitk_ws_floats, &a.kchunk);
         if (a.ksplit > 1) {
             a.partial = out.splitk_ws;
-            if (pre_scale) FD_TRY((launch_split_reg<64, 64, REG_PRE, true>(a, x_bytes, w_bytes, stream)));
+            const char* frag_k_env = getenv("FD_F32_BN_FRAG");
+            if (pre_scale && a.f32 == 1 && !(frag_k_env && atoi(frag_k_env) == 0) && a.stride == 1 && a.pad == 0 && a.K == a.Cin &&
+                a.K <= 2048)
+                FD_TRY((launch_split_glds_pre<64, 64, 4, 0, 2048>(a, x_bytes, w_bytes, stream)));
+            else if (pre_scale) FD_TRY((launch_split_reg<64, 64, REG_PRE, true>(a, x_bytes, w_bytes, stream)));
             else if (a.M >= 1024 && s.cout >= 512) FD_TRY((launch_split_glds<128, 128, 2, 4, true>(a, x_bytes, w_bytes, stream)));
             else FD_TRY((launch_split_glds<64, 64, 4, 4, true>(a, x_bytes, w_bytes, stream)));
             return split_k_finish(a, stream);
@@ -946,10 +1001,22 @@ static int split_conv_dispatch(const SplitConvParams& p, const void* x_split, co
             if (tile_pre_env == 1 && s.cout > 64) return launch_split_reg<128, 128, REG_PRE, true>(a, x_bytes, w_bytes, stream);
             if (tile_pre_env == 2) return launch_split_reg<128, 64, REG_PRE, true>(a, x_bytes, w_bytes, stream);
             if (tile_pre_env == 3) return launch_split_reg<64, 64, REG_PRE, true>(a, x_bytes, w_bytes, stream);
+            // FD_F32_BN_FRAG=0 (read at every call, so that a test can compare the two forms in one process): the
+            // register-staged kernel for every such layer
+            const char* frag_env = getenv("FD_F32_BN_FRAG");
+            const bool frag = !(frag_env && atoi(frag_env) == 0) && a.f32 == 1 && tile_pre_env == 0 && a.stride == 1 && a.pad == 0 &&
+                              a.K == a.Cin;
+            if (frag && s.cout > 64 && t128 >= 384 && a.K <= 1024)
+                return launch_split_glds_pre<128, 128, 2, 0, 1024>(a, x_bytes, w_bytes, stream);
+            if (frag && t12864 >= 1536 && a.K <= 256) return launch_split_glds_pre<128, 64, 2, 3, 256>(a, x_bytes, w_bytes, stream);
             if (s.cout > 64 && t128 >= 384) return launch_split_reg<128, 128, REG_PRE, true>(a, x_bytes, w_bytes, stream);
             // a single frame's 64-channel layers (1 013 tiles of 128 x 64): 59 -> 52 us on 64 x 64 tiles; from two
             // frames on the taller tile is as fast or faster
-            if (t12864 >= (s.cout <= 64 ? 1536 : 384)) return launch_split_reg<128, 64, REG_PRE, true>(a, x_bytes, w_bytes, stream);
+            if (t12864 >= (s.cout <= 64 ? 1536 : 384)) {
+                if (frag && a.K <= 1024) return launch_split_glds_pre<128, 64, 3, 0, 1024>(a, x_bytes, w_bytes, stream);
+                return launch_split_reg<128, 64, REG_PRE, true>(a, x_bytes, w_bytes, stream);
+            }
+            if (frag && a.K <= 2048) return launch_split_glds_pre<64, 64, 4, 0, 2048>(a, x_bytes, w_bytes, stream);
             return launch_split_reg<64, 64, REG_PRE, true>(a, x_bytes, w_bytes, stream);
         }
         if (a.f32 != 2 && tile_env) {

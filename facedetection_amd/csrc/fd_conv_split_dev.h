@@ -136,6 +136,38 @@ __device__ __forceinline__ void f32_mma_step(const char* stage, const int (&a_of
     }
 }
 
+// The float32 K-step on a raw input: BatchNorm + ReLU (v -> max(v * scale[k] + shift[k], 0)) on the activation
+// fragments between the LDS reads and the MFMAs.  `pre` points at this lane's four scale values of the step's
+// part 0 (channels 4 * (lane >> 4) .. + 3 of the 32); part 1 is 16 channels on, the shifts `shift_bytes` on.
+template <int BM, int BN>
+__device__ __forceinline__ void f32_mma_step_pre(const char* stage, const int (&a_off)[2], const int (&b_off)[2],
+                                                 f32x4 (&acc)[BM / 32][BN / 32], const char* pre, int shift_bytes) {
+    constexpr int AM = BM / 32, AN = BN / 32;
+#pragma unroll
+    for (int part = 0; part < 2; ++part) {
+        f32x4 av[AM], bv[AN];
+        const f32x4 sc = *reinterpret_cast<const f32x4*>(pre + part * 64);
+        const f32x4 sh = *reinterpret_cast<const f32x4*>(pre + shift_bytes + part * 64);
+#pragma unroll
+        for (int mi = 0; mi < AM; ++mi) av[mi] = *reinterpret_cast<const f32x4*>(stage + a_off[part] + mi * 2048);
+#pragma unroll
+        for (int ni = 0; ni < AN; ++ni) bv[ni] = *reinterpret_cast<const f32x4*>(stage + b_off[part] + ni * 2048);
+#pragma unroll
+        for (int mi = 0; mi < AM; ++mi)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) av[mi][t] = fmaxf(av[mi][t] * sc[t] + sh[t], 0.f);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int mi = 0; mi < AM; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < AN; ++ni)
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mi][t], bv[ni][t], acc[mi][ni], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+    }
+}
+
 // The same K-step on the bf16 matrix cores with float32-grade products ("bf16x3"): the staged operands are
 // the same float32 rows; each value v is cut in registers into three bf16 numbers
 //     hi = bf16(v),  mid = bf16(v - hi),  lo = bf16(v - hi - mid)        (round-to-nearest-even)
