@@ -9,13 +9,21 @@
 //   * the input transform V = B^T d B happens in registers, on the MFMA's activation fragments: a lane reads the
 //     two input rows a transform row i combines (8 float4 per 16-channel part), forms their combination and from it
 //     the fragments of the four transform columns j -- two LDS reads and four additions per fragment;
-//   * the 16 GEMMs M[i][j] = V[i][j] U[i][j]^T (32 patches x 64 channels x K = 64 each) run with the transformed
-//     weights streamed from L2 through two LDS stages, 8 KB per GEMM and K half; wave (wm, wx) owns 16 patches and
-//     the transform rows i = 2 wx, 2 wx + 1, i.e. 8 of the 16 accumulator sets (128 registers);
-//   * the output transform Y = A^T M A is linear in M, so each wave reduces its own 8 GEMMs in registers and the
-//     two waves of a patch block add their halves through LDS; bias + ReLU, and t2 lands in LDS as the A operand
-//     of the 1x1, which then runs exactly as in conv_tail_fused_kernel (64 output channels at a time, residual
-//     values requested ahead, transposed epilogue).
+//   * the 16 GEMMs M[i][j] = V[i][j] U[i][j]^T (32 patches x 64 channels x K = 64 each): wave (wm, wn) owns 16
+//     patches x 32 output channels of ALL of them, transform row i outermost, so only the four GEMMs of one row are
+//     live as accumulators (32 registers).  The transformed weights never touch LDS: a lane's fragments of a step
+//     (GEMM, K half) are 4 x 16 bytes that it reads straight from L2 into registers three steps ahead, from a copy
+//     packed in reading order (every load instruction fetches 1 KB of consecutive bytes) -- phase 1 has no barrier;
+//   * the output transform Y = A^T M A is linear in M: after each transform row the wave folds that row's column
+//     combination into its four output pixels per patch (32 registers), entirely in registers; bias + ReLU, and t2
+//     lands in LDS as the A operand of the 1x1, which then runs exactly as in conv_tail_fused_kernel (64 output
+//     channels at a time, residual values requested ahead, transposed epilogue).
+// Where a workgroup's time goes (wave 0's clock at the phase boundaries, averaged over 255 workgroups of a 16-frame
+// launch; alone on its CU / sharing it with a second workgroup as in production): input patch 2.0 / 5.1 us, the 16
+// GEMMs 9.9 / 14.0 us (6.8 us of matrix time), bias + ReLU + t2 0.65 / 1.5 us, first chunk of the 1x1 4.3 / 6.9 us,
+// chunks 2-4 11.4 / 18 us (1.7 us of matrix time each).  The form before this one -- the waves of a patch block
+// split the transform rows, weights through a two-stage LDS ring with a barrier per step, halves of the output
+// transform exchanged through LDS -- spent 10.6 / 13.3 us in the GEMMs and 2.8 / 7.4 us in the output transform.
 // F(2x2, 3x3)'s transforms are additions and halvings only: against float64 its error is the direct form's
 // (fd_winograd.hip).  Results differ from conv_tail_fused_kernel's in the last bits.
 #include "fd_conv_split_dev.h"
@@ -27,7 +35,7 @@ namespace fd {
 
 struct TailWinoArgs {
     const float* x;        // t1 [B][H][W][64], activated
-    const float* u;        // transformed weights [16][2][64][32]: GEMM xi = 4 i + j, K half, output channel, channel
+    const float* u;        // transformed weights in the lanes' reading order (tail_wino_pack)
     const float* bias2;    // [64]
     SplitKArgs c;          // the 1x1: w, bias, res, y32, ysplit, post_scale / post_shift, Cout, M, w_inv_scale
     int H, W, tiles_x, tiles_y;
@@ -42,21 +50,16 @@ __global__ __launch_bounds__(256, 2) void conv_tail_wino_kernel(TailWinoArgs k) 
     constexpr int PW = 18, PPIX = 180, PROWS = 192;
     constexpr int PLANE = PROWS * 128;                  // bytes per K-half plane of the input patch
     constexpr int D_BYTES = 2 * PLANE;                  // 48 KB
-    constexpr int U_OFF = D_BYTES, U_MAT = 64 * 128;    // one GEMM's weights for one K half: 8 KB
-    constexpr int U_STAGE = 2 * U_MAT;                  // both wave columns
-    constexpr int SMEM_BYTES = U_OFF + 2 * U_STAGE;     // 80 KB
-    constexpr int X_OFF = 0;                            // exchange of the output transform's halves (32 KB)
-    constexpr int A_OFF = U_OFF;                        // t2 as the 1x1's A operand: 2 K-steps x 128 rows x 128 B
+    constexpr int A_OFF = D_BYTES;                      // t2 as the 1x1's A operand: 2 K-steps x 128 rows x 128 B
+    constexpr int SMEM_BYTES = A_OFF + (MID / 32) * BM * 128;   // 80 KB
     constexpr int CS_BYTES = 20 * 1024;                 // epilogue staging / weight chunk of the 1x1, at offset 0
-    static_assert(SMEM_BYTES == 80 * 1024 && T::EPI * 4 <= CS_BYTES && CS_BYTES <= A_OFF &&
-                      A_OFF + (MID / 32) * BM * 128 <= SMEM_BYTES && 2 * 4 * 16 * 64 * 4 <= D_BYTES,
-                  "LDS plan");
+    static_assert(SMEM_BYTES == 80 * 1024 && T::EPI * 4 <= CS_BYTES && CS_BYTES <= A_OFF, "LDS plan");
     __shared__ __attribute__((aligned(16))) float smem[SMEM_BYTES / 4];
     char* const sbytes = reinterpret_cast<char*>(smem);
 
     const SplitKArgs& c = k.c;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wx = wave & 1;
+    const int wm = wave >> 1, wn = wave & 1;
     int wgid;
     {
         const int nwg = gridDim.x, bid = blockIdx.x;
@@ -93,48 +96,41 @@ __global__ __launch_bounds__(256, 2) void conv_tail_wino_kernel(TailWinoArgs k) 
                                                  16, vo, 0, 0, 0);
     }
 
-    // ---- transformed weights: step s = (ii, h, j) needs GEMM xi = (2 wx' + ii) * 4 + j, K half h, for both wx'
-    unsigned uvo[4];
-    int uwx[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int q = wave * 4 + i;                  // 0..15, uniform: wave column q >> 3, 8-row piece q & 7
-        uwx[i] = q >> 3;
-        const int row = (q & 7) * 8 + lrow;
-        uvo[i] = (unsigned)(row * 128 + ((lpos ^ ((row >> 1) & 7)) * 16));
-    }
-#define FD_UDMA(S)                                                                                \
+    // ---- transformed weights: step s = (i, h, j) multiplies by GEMM xi = 4 i + j, K half h.  A lane's four fragments of
+    // a step (part pl, 16-channel block ni: f = 2 pl + ni) come straight from memory (L2) into registers, 16 bytes each,
+    // in the packed order [s][wn][f][lane] -- every load instruction reads 1 KB of consecutive bytes -- and are requested
+    // PD - 1 steps ahead, so phase 1 has no LDS traffic for the weights and no barrier.
+    constexpr int PD = 4;
+    f32x4 bq[PD][4];
+    const unsigned blane = (unsigned)(lane * 16);
+#define FD_ULOAD(S)                                                                               \
     do {                                                                                          \
-        const int ii_ = (S) >> 3, h_ = ((S) >> 2) & 1, j_ = (S) & 3;                              \
-        _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                           \
-            const int xi_ = (2 * uwx[i] + ii_) * 4 + j_;                                          \
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(                                             \
-                ur, (__attribute__((address_space(3))) void*)(sbytes + U_OFF + ((S) & 1) * U_STAGE + (wave * 4 + i) * 1024), \
-                16, uvo[i], (xi_ * 2 + h_) * U_MAT, 0, 0);                                        \
-        }                                                                                         \
+        _Pragma("unroll") for (int f = 0; f < 4; ++f)                                             \
+            bq[(S) % PD][f] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(    \
+                ur, blane + f * 1024, ((S) * 2 + wn) * 4096, 0));                                 \
     } while (0)
+#pragma unroll
+    for (int st = 0; st < PD - 1; ++st) FD_ULOAD(st);
+    __builtin_amdgcn_sched_barrier(0);
+    wait_vmcnt<(PD - 1) * 4>();        // the input patch has landed (the weights requested after it may fly)
+    __syncthreads();
 
-    // ---- phase 1: the 16 GEMMs
+    // ---- phase 1: the 16 GEMMs, transform row i outermost; wave (wm, wn) owns 16 patches x 32 output channels
     // this lane's patch in the MFMA's row operand: block wm holds patch rows 2 wm, 2 wm + 1 (8 patches each)
     const int pyy = wm * 2 + (frow >> 3), pxx = frow & 7;
     const int r00 = (2 * pyy) * PW + 2 * pxx;       // patch row of the 4 x 4 input patch's top-left pixel (even)
-    f32x4 acc[8][4];
+    f32x4 y[4][2];          // [p * 2 + q][ni]: output pixel (p, q) of the patch, Y = A^T M A with A^T = (1, 1, 1, 0; 0, 1, -1, -1)
 #pragma unroll
-    for (int g = 0; g < 8; ++g)
-#pragma unroll
-        for (int ni = 0; ni < 4; ++ni) acc[g][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    FD_UDMA(0);
-    wait_vmcnt<0>();
-    __syncthreads();
-
-#pragma unroll
-    for (int ii = 0; ii < 2; ++ii) {
-        // transform row i = 2 wx + ii combines input rows a1 and a2: (0, -2), (1, +2), (2, -1), (1, -3)
-        const int i_ = 2 * wx + ii;
+    for (int i_ = 0; i_ < 4; ++i_) {
+        // transform row i combines input rows a1 and a2: (0, -2), (1, +2), (2, -1), (1, -3)
         const int a1 = (i_ == 0) ? 0 : (i_ == 2 ? 2 : 1);
         const int a2 = (i_ == 0 || i_ == 1) ? 2 : (i_ == 2 ? 1 : 3);
         const float s2 = (i_ == 1) ? 1.f : -1.f;
+        f32x4 acc[4][2];     // [j][ni]
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) acc[j][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             // activation fragments of this (i, K half): [part][j]
@@ -157,92 +153,71 @@ __global__ __launch_bounds__(256, 2) void conv_tail_wino_kernel(TailWinoArgs k) 
             }
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const int s = ii * 8 + h * 4 + j;
-                if (s + 1 < 16) FD_UDMA(s + 1);
-                const char* ub = sbytes + U_OFF + (s & 1) * U_STAGE + wx * U_MAT;
+                const int s = (i_ * 2 + h) * 4 + j;
+                if (s + PD - 1 < 32) FD_ULOAD(s + PD - 1);
+                __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-                for (int pl = 0; pl < 2; ++pl) {
-                    f32x4 bv[4];
-#pragma unroll
-                    for (int ni = 0; ni < 4; ++ni)
-                        bv[ni] = *reinterpret_cast<const f32x4*>(ub + (ni * 16 + frow) * 128 + (((pl * 4 + fh) ^ sw) << 4));
-                    __builtin_amdgcn_s_setprio(1);
+                for (int pl = 0; pl < 2; ++pl)
 #pragma unroll
                     for (int t = 0; t < 4; ++t)
 #pragma unroll
-                        for (int ni = 0; ni < 4; ++ni)
-                            acc[ii * 4 + j][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[pl][j][t], bv[ni][t], acc[ii * 4 + j][ni], 0, 0, 0);
-                    __builtin_amdgcn_s_setprio(0);
-                }
-                wait_vmcnt<0>();
-                __syncthreads();
+                        for (int ni = 0; ni < 2; ++ni)
+                            acc[j][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[pl][j][t], bq[s % PD][pl * 2 + ni][t], acc[j][ni], 0, 0, 0);
+                __builtin_amdgcn_s_setprio(0);
             }
         }
-    }
-#undef FD_UDMA
-
-    // ---- phase 2: output transform.  T[ii][q] = the row's column combination; this wave's share of
-    // Y[p][q] = sum_i A^T[p][i] T[i][q] with A^T = (1, 1, 1, 0; 0, 1, -1, -1).  (The barrier that ended the last
-    // step separates the reads of the patch from the exchange buffer that overlays it.)
-    float* const xbuf = smem + X_OFF / 4 + wm * (4 * 4 * 4 * 64);
-    f32x4 y[4][4];          // [p * 2 + q][ni]
+        // this row's share of the output transform: T[i][q] over the columns j, then Y[p][q] += A^T[p][i] T[i][q]
 #pragma unroll
-    for (int ni = 0; ni < 4; ++ni) {
-        f32x4 t[2][2];
-#pragma unroll
-        for (int ii = 0; ii < 2; ++ii) {
-            t[ii][0] = acc[ii * 4 + 0][ni] + acc[ii * 4 + 1][ni] + acc[ii * 4 + 2][ni];
-            t[ii][1] = acc[ii * 4 + 1][ni] - acc[ii * 4 + 2][ni] - acc[ii * 4 + 3][ni];
-        }
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            if (wx == 0) {
-                y[0 + q][ni] = t[0][q] + t[1][q];
-                y[2 + q][ni] = t[1][q];
+        for (int ni = 0; ni < 2; ++ni) {
+            const f32x4 t0 = acc[0][ni] + acc[1][ni] + acc[2][ni];
+            const f32x4 t1 = acc[1][ni] - acc[2][ni] - acc[3][ni];
+            if (i_ == 0) {
+                y[0][ni] = t0; y[1][ni] = t1;
+            } else if (i_ == 1) {
+                y[0][ni] += t0; y[1][ni] += t1; y[2][ni] = t0; y[3][ni] = t1;
+            } else if (i_ == 2) {
+                y[0][ni] += t0; y[1][ni] += t1; y[2][ni] -= t0; y[3][ni] -= t1;
             } else {
-                y[0 + q][ni] = t[0][q];
-                y[2 + q][ni] = -t[0][q] - t[1][q];
+                y[2][ni] -= t0; y[3][ni] -= t1;
             }
         }
     }
-    if (wx == 1) {
+#undef FD_ULOAD
+
+    // ---- phase 2: bias + ReLU; t2 lands in LDS as the A operand of the 1x1 (behind the input patch, which other waves
+    // may still be reading): channel half wn, swizzled 128-byte rows like every operand image
+    {
+        float b2[2];
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) b2[ni] = k.bias2 ? k.bias2[wn * 32 + ni * 16 + frow] : 0.f;
 #pragma unroll
         for (int pq = 0; pq < 4; ++pq)
 #pragma unroll
-            for (int ni = 0; ni < 4; ++ni)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) xbuf[((pq * 4 + ni) * 4 + r) * 64 + lane] = y[pq][ni][r];
-    }
-    __syncthreads();
-    if (wx == 0) {
-        float b2[4];
-#pragma unroll
-        for (int ni = 0; ni < 4; ++ni) b2[ni] = k.bias2 ? k.bias2[ni * 16 + frow] : 0.f;
-#pragma unroll
-        for (int pq = 0; pq < 4; ++pq)
-#pragma unroll
-            for (int ni = 0; ni < 4; ++ni)
+            for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float v = fmaxf(y[pq][ni][r] + xbuf[((pq * 4 + ni) * 4 + r) * 64 + lane] + b2[ni], 0.f);
+                    const float v = fmaxf(y[pq][ni][r] + b2[ni], 0.f);
                     // accumulator row (lane >> 4) * 4 + r = patch of this block; column = output channel
                     const int pm = fh * 4 + r;
                     const int prow = (2 * (wm * 2 + (pm >> 3)) + (pq >> 1)) * 16 + 2 * (pm & 7) + (pq & 1);
-                    const int c32 = (ni & 1) * 16 + frow;
-                    *reinterpret_cast<float*>(sbytes + A_OFF + (ni >> 1) * (BM * 128) + prow * 128 +
+                    const int c32 = ni * 16 + frow;
+                    *reinterpret_cast<float*>(sbytes + A_OFF + wn * (BM * 128) + prow * 128 +
                                               (((c32 >> 2) ^ ((prow >> 1) & 7)) << 4) + (c32 & 3) * 4) = v;
                 }
     }
 
     // ---- phase 3: the 1x1 convolution, 64 output channels at a time, as conv_tail_fused_kernel's float32 form: the
     // weight chunk shares the LDS of the epilogue staging and is fetched after the previous chunk's epilogue.
-    // Measured and not kept (1.55-1.69 ms per unit as it is): the chunk in LDS of its own with chunk ch + 1 and its
+    // Measured and not kept (1.47-1.60 ms per unit as it is): the chunk in LDS of its own with chunk ch + 1 and its
     // residual values requested before the epilogue of chunk ch, barriers and epilogue that do not drain the
-    // vector-memory counter (1.60-1.72 ms); the residual values of all four chunks requested at once into the
-    // registers the accumulators leave (1.65-1.74 ms).  The kernel is within 1.5x of both of its floors -- 0.89 ms of
-    // matrix time, 1.04 ms of HBM time for 4.9 GB -- and what separates it from them is that a CU's two workgroups
-    // overlap their matrix and memory phases only by chance; staggering their start changed nothing.
-    const int wn = wx;
+    // vector-memory counter; the residual values of all four chunks requested at once into the registers the
+    // accumulators leave; the 1x1's weights as register fragments a chunk ahead, like the 3x3's, with the staging
+    // slices laid over the dead input patch so that one barrier serves all four chunks (1.57-1.67 ms: a chunk costs
+    // 3.5 us alone on a CU with or without its weight wait and barriers -- 1.7 us of matrix time and the round trip
+    // of its residual values).  The kernel is within 1.5x of both of its floors -- 0.89 ms of matrix time, 1.04 ms
+    // of HBM time for 4.9 GB -- and what separates it from them is that a CU's two workgroups overlap their matrix
+    // and memory phases only by chance; staggering their start changed nothing, and without the raised priority of
+    // the MFMA blocks the GEMM phase of one workgroup starves behind the other's epilogue (14 -> 24 us).
     float* wch = smem;
     int a3_off[MID / 32][2], b3_off[MID / 32][2];
 #pragma unroll
@@ -285,18 +260,25 @@ __global__ __launch_bounds__(256, 2) void conv_tail_wino_kernel(TailWinoArgs k) 
 #endif
 }
 
-// Transformed weights of the 3x3 in the kernel's layout: U[xi][h][o][c32] = (G g G^T)[i][j] of filter (o, 32 h + c32)
-// times out_scale[o], from wino_pack_weights' [16][cout_pad][64].
+// Transformed weights of the 3x3 in the order the kernel's lanes read them: [step s = (i, h, j)][wn][f = 2 pl + ni][lane][t]
+// holds (G g G^T)[i][j] of filter (o, c) times out_scale[o] with o = 32 wn + 16 ni + (lane & 15) and
+// c = 32 h + 16 pl + 4 (lane >> 4) + t; built from wino_pack_weights' [16][cout_pad][64].
 int tail_wino_pack(const float* w_oihw, const float* out_scale, std::vector<float>* packed) {
     std::vector<float> u;
     int cout_pad = 0;
     FD_TRY(wino_pack_weights(w_oihw, 64, 64, out_scale, 2, &u, &cout_pad));
-    packed->assign((size_t)16 * 2 * 64 * 32, 0.f);
-    for (int xi = 0; xi < 16; ++xi)
-        for (int h = 0; h < 2; ++h)
-            for (int o = 0; o < 64; ++o)
-                for (int cc = 0; cc < 32; ++cc)
-                    (*packed)[(((size_t)xi * 2 + h) * 64 + o) * 32 + cc] = u[((size_t)xi * cout_pad + o) * 64 + h * 32 + cc];
+    packed->assign((size_t)32 * 2 * 4 * 64 * 4, 0.f);
+    for (int s = 0; s < 32; ++s) {
+        const int i = s >> 3, h = (s >> 2) & 1, j = s & 3, xi = i * 4 + j;
+        for (int wn = 0; wn < 2; ++wn)
+            for (int f = 0; f < 4; ++f)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int t = 0; t < 4; ++t) {
+                        const int o = wn * 32 + (f & 1) * 16 + (lane & 15);
+                        const int c = h * 32 + (f >> 1) * 16 + (lane >> 4) * 4 + t;
+                        (*packed)[((((size_t)s * 2 + wn) * 4 + f) * 64 + lane) * 4 + t] = u[((size_t)xi * cout_pad + o) * 64 + c];
+                    }
+    }
     return FD_OK;
 }
 
