@@ -338,9 +338,11 @@ __device__ __forceinline__ void conv_split_glds_body(const SplitKArgs& a, unsign
     const int tile_n = (wgid / a.ksplit) % a.tiles_n, tile_m = wgid / (a.ksplit * a.tiles_n);
 
     if constexpr (PREK > 0) {
-        // scale | shift of every input channel (before any LDS-DMA is issued: these are ordinary loads, and the
-        // first barrier of the pipeline below publishes them)
-        for (int i = tid * 4; i < a.K; i += WAVES * 256) {
+        // scale | shift of the input channels this workgroup multiplies (all of them unless the launch splits K;
+        // before any LDS-DMA is issued: these are ordinary loads, and the first barrier of the pipeline below
+        // publishes them)
+        const int c0 = ks * a.kchunk * SBK, c1 = min(a.K, c0 + a.kchunk * SBK);
+        for (int i = c0 + tid * 4; i < c1; i += WAVES * 256) {
             *reinterpret_cast<f32x4*>(smem + SMEM + i) = *reinterpret_cast<const f32x4*>(a.pre_scale + i);
             *reinterpret_cast<f32x4*>(smem + SMEM + PREK + i) = *reinterpret_cast<const f32x4*>(a.pre_shift + i);
         }
@@ -985,11 +987,9 @@ static int split_conv_dispatch(const SplitConvParams& p, const void* x_split, co
         a.ksplit = choose_split_k(ho * wo, a.K / SBK, (long long)a.M * s.cout, out.splitk_ws_floats, &a.kchunk);
         if (a.ksplit > 1) {
             a.partial = out.splitk_ws;
-            const char* frag_k_env = getenv("FD_F32_BN_FRAG");
-            if (pre_scale && a.f32 == 1 && !(frag_k_env && atoi(frag_k_env) == 0) && a.stride == 1 && a.pad == 0 && a.K == a.Cin &&
-                a.K <= 2048)
-                FD_TRY((launch_split_glds_pre<64, 64, 4, 0, 2048>(a, x_bytes, w_bytes, stream)));
-            else if (pre_scale) FD_TRY((launch_split_reg<64, 64, REG_PRE, true>(a, x_bytes, w_bytes, stream)));
+            // (BatchNorm on load with K split: the register-staged kernel is the faster one, 58 against 63 us on the
+            // ROI head's K = 2048 layers at 160 rois, the same at 10)
+            if (pre_scale) FD_TRY((launch_split_reg<64, 64, REG_PRE, true>(a, x_bytes, w_bytes, stream)));
             else if (a.M >= 1024 && s.cout >= 512) FD_TRY((launch_split_glds<128, 128, 2, 4, true>(a, x_bytes, w_bytes, stream)));
             else FD_TRY((launch_split_glds<64, 64, 4, 4, true>(a, x_bytes, w_bytes, stream)));
             return split_k_finish(a, stream);
@@ -1016,7 +1016,9 @@ static int split_conv_dispatch(const SplitConvParams& p, const void* x_split, co
                 if (frag && a.K <= 1024) return launch_split_glds_pre<128, 64, 3, 0, 1024>(a, x_bytes, w_bytes, stream);
                 return launch_split_reg<128, 64, REG_PRE, true>(a, x_bytes, w_bytes, stream);
             }
-            if (frag && a.K <= 2048) return launch_split_glds_pre<64, 64, 4, 0, 2048>(a, x_bytes, w_bytes, stream);
+            // (64 output channels on 64 x 64 tiles, a single frame's layers of the 64-channel stage: 52-53 us on the
+            // register-staged kernel, 56-58 us on this one; with 256 channels 41 against 48.5 us)
+            if (frag && s.cout > 64 && a.K <= 2048) return launch_split_glds_pre<64, 64, 4, 0, 2048>(a, x_bytes, w_bytes, stream);
             return launch_split_reg<64, 64, REG_PRE, true>(a, x_bytes, w_bytes, stream);
         }
         if (a.f32 != 2 && tile_env) {

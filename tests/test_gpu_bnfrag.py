@@ -19,8 +19,8 @@ CASES = [
     (7, 67, 119, 1024, 256, True, True, True),      # ragged
     (1, 68, 120, 1024, 256, True, True, True),      # a single frame: 64 x 64 tiles
     (1, 135, 240, 512, 128, True, True, True),      # ... 128 x 64 tiles, two workgroups per CU
-    (1, 270, 480, 256, 64, True, True, True),       # ... 64 x 64 tiles, 64 output channels
-    (10, 7, 7, 2048, 512, True, True, True),        # the ROI head's layer: K split over workgroups
+    (1, 270, 480, 256, 64, True, True, False),      # ... 64 output channels on 64 x 64 tiles: register-staged kernel
+    (10, 7, 7, 2048, 512, True, True, True),        # the ROI head's layer (K unsplit through this entry point)
     (2, 14, 14, 4096, 512, True, True, False),      # more channels than the fragment kernel keeps in LDS
 ]
 
