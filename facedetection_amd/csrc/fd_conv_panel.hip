@@ -304,8 +304,10 @@ bool conv_panel_applies(const SplitKArgs& a) {
     // (the batched K = 128 GEMMs of the Winograd layers -- four chunks, no residual -- ran 13 % slower here than on
     // the three-workgroup tile: 391 -> 443 us)
     if (a.wbatch_tiles > 0) return false;
-    // several rounds of panels per CU: a panel's own prologue is covered by the CU's other workgroup only
-    return ceil_div(a.M, bm) >= 1024;
+    // from most of one round of resident workgroups (2 x 256) on: a single 1080p frame's 507 panels take 46 us here
+    // and 53-58 us as 1 016 tiles of the general kernel (FD_F32_PANEL_MIN moves the limit for probes)
+    static const int panel_min = getenv("FD_F32_PANEL_MIN") ? atoi(getenv("FD_F32_PANEL_MIN")) : 448;
+    return ceil_div(a.M, bm) >= panel_min;
 }
 
 int conv_panel_forward(const SplitKArgs& a, size_t x_bytes, size_t w_bytes, hipStream_t stream) {

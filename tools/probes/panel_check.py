@@ -15,7 +15,7 @@ sys.path.insert(0, ROOT)
 
 # (B, H, W, Cin, Cout, stride, bias, relu, residual)
 SHAPES = [
-    (5, 135, 240, 128, 512, 1, False, False, True),      # last convolution of a 128-channel unit (too few panels: general kernel)
+    (5, 135, 240, 128, 512, 1, False, False, True),      # last convolution of a 128-channel unit
     (16, 135, 240, 128, 512, 1, False, False, True),     # ... at the benchmark's micro-batch
     (8, 270, 480, 64, 256, 1, False, False, False),      # projection shortcut of the 64-channel stage
     (8, 270, 480, 128, 256, 2, True, True, False),       # stride 2, bias + ReLU
