@@ -3,7 +3,7 @@
 fused tails or whole-unit kernels, Winograd layers, the large tiles) against the layer-by-layer pass of the same
 detector, in either precision.  Prints the worst relative difference per tensor; exits non-zero above 3e-5.
 
-    python tools/fuzz_paths.py [cases=12] [seed=0] [precision=f32]
+    python tools/fuzz_paths.py [cases=12] [seed=0] [precision=f32] [max_h=420] [max_w=700] [max_batch=3]
 """
 import os
 import sys
@@ -18,6 +18,9 @@ def main():
     cases = int(sys.argv[1]) if len(sys.argv) > 1 else 12
     rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
     precision = sys.argv[3] if len(sys.argv) > 3 else "f32"
+    max_h = int(sys.argv[4]) if len(sys.argv) > 4 else 420
+    max_w = int(sys.argv[5]) if len(sys.argv) > 5 else 700
+    max_b = int(sys.argv[6]) if len(sys.argv) > 6 else 3
     lay = Detector("synthetic:0", 0, own_context=True, precision=precision, on_clamp="raise")
     new = Detector("synthetic:0", 0, own_context=True, precision=precision, on_clamp="raise")
     lay.keep_tensors(True)
@@ -25,8 +28,8 @@ def main():
     worst = {}
     try:
         for _ in range(cases):
-            b = int(rng.integers(1, 4))
-            h, w = int(rng.integers(32, 420)), int(rng.integers(32, 700))
+            b = int(rng.integers(1, max_b + 1))
+            h, w = int(rng.integers(32, max_h)), int(rng.integers(32, max_w))
             frames = rng.integers(0, 256, size=(b, h, w, 3), dtype=np.uint8)
             lay.forward(frames)
             new.forward(frames)
