@@ -18,6 +18,7 @@ cd /tmp && export TMPDIR=/tmp
 timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d $OUT/kt2 -- python3 $R/bench.py --frames 16 --steps 1 --warmup 1 --no-cpu-baseline --no-profile --check-frames 0 --no-split-record --no-b3-record --no-config-records > $OUT/b16.json 2> $OUT/b16.err
 cd $R
 python3 tools/conv_layer_report.py $(ls $OUT/kt2/*/*kernel_trace.csv | head -1) 16 f32 > $OUT/layers_f32.txt 2>&1 || true
+python3 tools/ridge_table.py $OUT/layers_f32.txt 16 > $OUT/ridge_f32.txt 2>&1 || true
 rm -rf $OUT/kt2
 cd /tmp
 timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d $OUT/kt3 -- python3 $R/bench.py --precision f16x3 --streams 1 --frames 16 --steps 1 --warmup 1 --no-cpu-baseline --no-profile --check-frames 0 --no-split-record --no-b3-record --no-config-records > $OUT/b16s.json 2> $OUT/b16s.err

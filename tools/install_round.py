@@ -12,7 +12,7 @@ src, dst = os.path.join(ROOT, "gpurun_out", tag), os.path.join(ROOT, "profiles")
 for name in ("kernel_stats.csv", "kernel_stats_headline.csv", "bench_headline_under_rocprof.json", "bench.json", "bench_under_rocprof.json", "pmc_traffic.json", "bench_two_streams.json",
              "frontend.json", "frontend_128.json", "bench_direct.json", "bench_from_host.json", "frontend_pmc_traffic.json", "pmc_traffic_f32.json"):
     shutil.copy(os.path.join(src, name), os.path.join(dst, "%s_%s" % (tag, name)))
-for name in ("layers_f32.txt", "layers_f16x3.txt"):
+for name in ("layers_f32.txt", "layers_f16x3.txt", "ridge_f32.txt"):
     if os.path.exists(os.path.join(src, name)):
         shutil.copy(os.path.join(src, name), os.path.join(dst, "%s_%s" % (tag, name)))
 # SQ-counter table of the float32 pass: header with the command, then the table tools/sq_summary.py printed on the box
