@@ -24,6 +24,9 @@
 // chunks 2-4 11.4 / 18 us (1.7 us of matrix time each).  The form before this one -- the waves of a patch block
 // split the transform rows, weights through a two-stage LDS ring with a barrier per step, halves of the output
 // transform exchanged through LDS -- spent 10.6 / 13.3 us in the GEMMs and 2.8 / 7.4 us in the output transform.
+// SC (the stride-1 projection unit, the first of the stage): y = conv1x1(t2) + conv1x1_sc(act) is ONE 1x1 over the 128
+// channels [t2 | act] with the weight rows [W3 | Wsc]; the shortcut tensor (2.1 GB per 16 frames at 1080p) is neither
+// written by a launch of its own nor read back as a residual.  933 + 1 500 us -> 2 003 us for the unit, +1.8 % frames/s.
 // F(2x2, 3x3)'s transforms are additions and halvings only: against float64 its error is the direct form's
 // (fd_winograd.hip).  Results differ from conv_tail_fused_kernel's in the last bits.
 #include "fd_conv_split_dev.h"
@@ -40,8 +43,10 @@ struct TailWinoArgs {
     SplitKArgs c;          // the 1x1: w, bias, res, y32, ysplit, post_scale / post_shift, Cout, M, w_inv_scale
     int H, W, tiles_x, tiles_y;
     unsigned x_bytes, u_bytes, w3_bytes;
+    const float* act;      // SC: the unit's activated input [B][H][W][64], the projection shortcut's operand
 };
 
+template <bool SC>
 __global__ __launch_bounds__(256, 2) void conv_tail_wino_kernel(TailWinoArgs k) {
 #if defined(__HIP_DEVICE_COMPILE__)
     constexpr int BM = 128, BN = 64, MID = 64;
@@ -52,8 +57,9 @@ __global__ __launch_bounds__(256, 2) void conv_tail_wino_kernel(TailWinoArgs k) 
     constexpr int D_BYTES = 2 * PLANE;                  // 48 KB
     constexpr int A_OFF = D_BYTES;                      // t2 as the 1x1's A operand: 2 K-steps x 128 rows x 128 B
     constexpr int SMEM_BYTES = A_OFF + (MID / 32) * BM * 128;   // 80 KB
-    constexpr int CS_BYTES = 20 * 1024;                 // epilogue staging / weight chunk of the 1x1, at offset 0
-    static_assert(SMEM_BYTES == 80 * 1024 && T::EPI * 4 <= CS_BYTES && CS_BYTES <= A_OFF, "LDS plan");
+    constexpr int KK3 = SC ? 4 : 2;                     // K-steps of the 1x1: t2's 64 channels (+ the shortcut operand's 64)
+    constexpr int CS_BYTES = SC ? 32 * 1024 : 20 * 1024; // epilogue staging / weight chunk of the 1x1, at offset 0
+    static_assert(SMEM_BYTES == 80 * 1024 && T::EPI * 4 <= CS_BYTES && KK3 * 64 * 128 <= CS_BYTES && CS_BYTES <= A_OFF, "LDS plan");
     __shared__ __attribute__((aligned(16))) float smem[SMEM_BYTES / 4];
     char* const sbytes = reinterpret_cast<char*>(smem);
 
@@ -184,6 +190,27 @@ __global__ __launch_bounds__(256, 2) void conv_tail_wino_kernel(TailWinoArgs k) 
     }
 #undef FD_ULOAD
 
+    // SC (the stride-1 projection unit): the shortcut convolution of the unit's activated input joins the 1x1 as 64
+    // more channels of K -- y = [t2 | act] [W3 | Wsc]^T -- so neither the shortcut tensor nor a residual read exists.
+    // The operand's fragments do not depend on the output chunk: a lane fetches its 16 pieces of 16 bytes (4 row
+    // blocks x 2 K-steps x 2 parts; pixels outside the picture read zeros) once, here, into the registers phase 1
+    // has released, and uses them for all chunks.
+    f32x4 xa[SC ? 4 : 1][2][2];
+    if constexpr (SC) {
+        const __amdgpu_buffer_rsrc_t ar = __builtin_amdgcn_make_buffer_rsrc((void*)k.act, 0, k.x_bytes, 0x00020000);
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) {
+            const int row = wm * 64 + mi * 16 + frow, ty = row >> 4, tx = row & 15;
+            const bool ok = y0 + ty < H && x0 + tx < W;
+            const unsigned vo = ok ? (unsigned)((((img * H + y0 + ty) * W + x0 + tx) * MID + fh * 4) * 4) : OOB;
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                for (int part = 0; part < 2; ++part)
+                    xa[mi][kk][part] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ar, vo + kk * 128 + part * 64, 0, 0));
+        }
+    }
+
     // ---- phase 2: bias + ReLU; t2 lands in LDS as the A operand of the 1x1 (behind the input patch, which other waves
     // may still be reading): channel half wn, swizzled 128-byte rows like every operand image
     {
@@ -219,31 +246,31 @@ __global__ __launch_bounds__(256, 2) void conv_tail_wino_kernel(TailWinoArgs k) 
     // and memory phases only by chance; staggering their start changed nothing, and without the raised priority of
     // the MFMA blocks the GEMM phase of one workgroup starves behind the other's epilogue (14 -> 24 us).
     float* wch = smem;
-    int a3_off[MID / 32][2], b3_off[MID / 32][2];
+    int a3_off[MID / 32][2], b3_off[KK3][2];
 #pragma unroll
-    for (int kk = 0; kk < MID / 32; ++kk)
+    for (int kk = 0; kk < KK3; ++kk)
 #pragma unroll
         for (int part = 0; part < 2; ++part) {
             const int pos = ((part * 4 + fh) ^ sw) * 16;
-            a3_off[kk][part] = A_OFF + kk * (BM * 128) + (wm * (BM / 2) + frow) * 128 + pos;
+            if (kk < MID / 32) a3_off[kk][part] = A_OFF + kk * (BM * 128) + (wm * (BM / 2) + frow) * 128 + pos;
             b3_off[kk][part] = kk * (64 * 128) + (wn * 32 + frow) * 128 + pos;
         }
-    constexpr int RL = E::GROUPS * E::PASSES * 2;        // residual loads per chunk and lane
+    constexpr int RL = SC ? 0 : E::GROUPS * E::PASSES * 2;        // residual loads per chunk and lane
     const int nch = c.Cout / 64;
     const PatchRows rows{(img * H + y0) * W + x0, W, min(8, H - y0), min(16, W - x0)};
     f32x4 res[E::GROUPS][E::PASSES][2];
     for (int ch = 0; ch < nch; ++ch) {
         __syncthreads();               // the shared region is free: phase 2 / the previous epilogue are done with it
 #pragma unroll
-        for (int kk = 0; kk < MID / 32; ++kk)
+        for (int kk = 0; kk < KK3; ++kk)
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 const int row = (wave + 4 * i) * 8 + lrow;
-                const unsigned vo = (unsigned)(((ch * 64 + row) * MID + kk * 32) * 4 + (lpos ^ ((row >> 1) & 7)) * 16);
+                const unsigned vo = (unsigned)(((ch * 64 + row) * (KK3 * 32) + kk * 32) * 4 + (lpos ^ ((row >> 1) & 7)) * 16);
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(
                     w3r, (__attribute__((address_space(3))) void*)(wch + kk * (64 * 32) + (wave + 4 * i) * 256), 16, vo, 0, 0, 0);
             }
-        split_residual_prefetch<BM, BN>(c, rows, ch, wave, lane, res);
+        if constexpr (!SC) split_residual_prefetch<BM, BN>(c, rows, ch, wave, lane, res);
         __builtin_amdgcn_sched_barrier(0);
         wait_vmcnt<RL>();              // weights of this chunk landed; its residual may fly
         __syncthreads();
@@ -254,8 +281,29 @@ __global__ __launch_bounds__(256, 2) void conv_tail_wino_kernel(TailWinoArgs k) 
             for (int ni = 0; ni < T::AN; ++ni) acc3[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int kk = 0; kk < MID / 32; ++kk) f32_mma_step<BM, BN>(sbytes, a3_off[kk], b3_off[kk], acc3);
+        if constexpr (SC) {
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                for (int part = 0; part < 2; ++part) {
+                    f32x4 bv[T::AN];
+#pragma unroll
+                    for (int ni = 0; ni < T::AN; ++ni)
+                        bv[ni] = *reinterpret_cast<const f32x4*>(sbytes + b3_off[MID / 32 + kk][part] + ni * 2048);
+                    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                    for (int t = 0; t < 4; ++t)
+#pragma unroll
+                        for (int mi = 0; mi < T::AM; ++mi)
+#pragma unroll
+                            for (int ni = 0; ni < T::AN; ++ni)
+                                acc3[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[mi][kk][part][t], bv[ni][t], acc3[mi][ni], 0, 0, 0);
+                    __builtin_amdgcn_s_setprio(0);
+                }
+        }
         // (the epilogue's own first barrier separates the last weight read from the staging writes)
-        split_epilogue16_rows<BM, BN, true>(c, smem, rows, ch, wave, lane, acc3, res);
+        if constexpr (SC) split_epilogue16_rows<BM, BN, false>(c, smem, rows, ch, wave, lane, acc3);
+        else split_epilogue16_rows<BM, BN, true>(c, smem, rows, ch, wave, lane, acc3, res);
     }
 #endif
 }
@@ -283,20 +331,23 @@ int tail_wino_pack(const float* w_oihw, const float* out_scale, std::vector<floa
 }
 
 int conv_tail_wino_forward(const float* u_wino, const float* bias2, const SplitConvParams& p3, const float* t1, int batch, int h,
-                           int w, const float* residual, const SplitConvOut& out, hipStream_t stream, bool* taken) {
+                           int w, const float* residual, const SplitConvOut& out, hipStream_t stream, bool* taken,
+                           const float* sc_act, const float* w3_sc) {
     *taken = false;
     const ConvShape& s3 = p3.s;
-    if (!u_wino || !p3.f32 || out.b3 || !residual ||
+    const bool sc = sc_act && w3_sc;      // the projection shortcut inside the 1x1 (no residual tensor then)
+    if (!u_wino || !p3.f32 || out.b3 || (sc ? residual != nullptr : !residual) ||
         !(s3.cin == 64 && s3.kh == 1 && s3.kw == 1 && s3.stride == 1 && s3.pad == 0 && s3.cout % 64 == 0))
         return FD_OK;
     const long long m_ll = (long long)batch * h * w;
-    const size_t x_bytes = (size_t)m_ll * 64 * 4, w3_bytes = s3.packed_floats() * 4;
+    const size_t x_bytes = (size_t)m_ll * 64 * 4, w3_bytes = s3.packed_floats() * 4 * (sc ? 2 : 1);
     if (x_bytes >= (1ull << 31) || m_ll >= (1ll << 29)) return FD_OK;
     FD_REQUIRE(t1 && p3.w && (out.y32 || out.ysplit), "Winograd tail: NULL tensor");
     TailWinoArgs k;
     k.x = t1; k.u = u_wino; k.bias2 = bias2;
     SplitKArgs& c = k.c;
-    c.x = nullptr; c.w = static_cast<const uint8_t*>(p3.w); c.bias = p3.bias; c.res = residual; c.y32 = out.y32;
+    c.x = nullptr; c.w = static_cast<const uint8_t*>(sc ? (const void*)w3_sc : p3.w); c.bias = p3.bias; c.res = residual; c.y32 = out.y32;
+    k.act = sc ? sc_act : nullptr;
     c.ysplit = static_cast<uint8_t*>(out.ysplit); c.post_scale = out.post_scale; c.post_shift = out.post_shift;
     c.pre_scale = c.pre_shift = nullptr; c.w_inv_scale = p3.w_inv_scale;
     c.H = h; c.W = w; c.Cin = 64; c.Ho = h; c.Wo = w; c.Cout = s3.cout; c.KW = 1; c.stride = 1; c.pad = 0; c.K = 64;
@@ -306,10 +357,12 @@ int conv_tail_wino_forward(const float* u_wino, const float* bias2, const SplitC
     k.x_bytes = (unsigned)x_bytes; k.u_bytes = 16u * 2u * 64u * 32u * 4u; k.w3_bytes = (unsigned)w3_bytes;
     // FLOPs executed: 16 GEMMs of (patches x 64 x 64) + the 1x1
     const double patches = (double)batch * k.tiles_x * k.tiles_y * 32.0;
-    ProfScope scope(stream, "conv_tail_wino_f32", 2.0 * 16.0 * patches * 64.0 * 64.0 + 2.0 * m_ll * (double)s3.cout * 64.0,
-                    4.0 * 64.0 * m_ll + 4.0 * 64.0 * (16.0 * 64.0 + s3.cout) +
-                        4.0 * m_ll * s3.cout * (1.0 + (c.y32 ? 1.0 : 0.0) + (c.ysplit ? 1.0 : 0.0)));
-    hipLaunchKernelGGL(conv_tail_wino_kernel, dim3(batch * k.tiles_x * k.tiles_y), dim3(256), 0, stream, k);
+    ProfScope scope(stream, sc ? "conv_tail_wino_sc_f32" : "conv_tail_wino_f32",
+                    2.0 * 16.0 * patches * 64.0 * 64.0 + 2.0 * m_ll * (double)s3.cout * (sc ? 128.0 : 64.0),
+                    4.0 * 64.0 * m_ll * (sc ? 2.0 : 1.0) + 4.0 * 64.0 * (16.0 * 64.0 + s3.cout * (sc ? 2.0 : 1.0)) +
+                        4.0 * m_ll * s3.cout * ((sc ? 0.0 : 1.0) + (c.y32 ? 1.0 : 0.0) + (c.ysplit ? 1.0 : 0.0)));
+    if (sc) hipLaunchKernelGGL(conv_tail_wino_kernel<true>, dim3(batch * k.tiles_x * k.tiles_y), dim3(256), 0, stream, k);
+    else hipLaunchKernelGGL(conv_tail_wino_kernel<false>, dim3(batch * k.tiles_x * k.tiles_y), dim3(256), 0, stream, k);
     FD_LAUNCH_CHECK();
     *taken = true;
     return FD_OK;

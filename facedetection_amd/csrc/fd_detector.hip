@@ -26,6 +26,7 @@ struct Unit {
     SplitConvParams f_conv1, f_conv2, f_conv3, f_sc;   // float32 operands on the same kernels
     WinoConvParams w_conv2;                            // conv2 in Winograd form (wide stride-1 layers only; both precisions)
     const float* tailw_u = nullptr;                    // 64-channel units: conv2's F(2x2,3x3) weights for the fused float32 tail
+    const float* tailw_w3sc = nullptr;                 // ... of the stride-1 projection unit: [cout][conv3's 64 | shortcut's 64] weights
     const float* pair_w = nullptr;                     // stride-1 projection units: shortcut rows + conv1 rows, one float32 GEMM
     size_t pair_w_floats = 0;
     const float *bn1_scale = nullptr, *bn1_shift = nullptr;   // the unit's input BatchNorm (device)
@@ -274,6 +275,15 @@ static int build_unit(fd_detector* d, const ParamTable& t, const std::string& na
         FD_TRY(make_conv(d, ws->data_host, cin, shape(cin, cout, 1, stride, 0), nullptr, nullptr, 0, &u->sc, &u->s_sc, &u->f_sc));
         u->sc.pre_scale = pre_s;
         u->sc.pre_shift = pre_h;
+        if (stride == 1 && mid == 64 && cin == 64 && u->tailw_u && u->f_sc.w && u->f_conv3.w && !u->f_sc.bias) {
+            // the shortcut inside the float32 tail: conv3's and the shortcut's weight rows side by side (K = 64 + 64)
+            float* pw = nullptr;
+            FD_HIP(hipMalloc((void**)&pw, (size_t)cout * 128 * sizeof(float)));
+            d->owned.push_back(pw);
+            FD_HIP(hipMemcpy2D(pw, 128 * sizeof(float), u->f_conv3.w, 64 * sizeof(float), 64 * sizeof(float), cout, hipMemcpyDeviceToDevice));
+            FD_HIP(hipMemcpy2D(pw + 64, 128 * sizeof(float), u->f_sc.w, 64 * sizeof(float), 64 * sizeof(float), cout, hipMemcpyDeviceToDevice));
+            u->tailw_w3sc = pw;
+        }
         if (stride == 1 && mid <= 64 && cout % 64 == 0 && u->f_sc.w && u->f_conv1.w) {
             // the shortcut and conv1 read the same tensor: their float32 weight rows in one buffer, conv1's padded to 64
             const size_t k = (size_t)cin;
@@ -575,9 +585,16 @@ static int run_unit_split(Plan& pl, const Unit& u, const char* name, const void*
         FD_TRY(unit_proj_fused_forward(c1, c2, c3, csc, act, n, h, w, y32, pl.d->clamped,
                                        pl.stream, &whole_proj));
     bool pair_done = false;
+    // float32, the stride-1 projection unit: the shortcut convolution runs inside the Winograd tail as 64 more channels
+    // of its 1x1 (FD_TAIL_SC=0, read at every call: the shortcut as a launch of its own and a residual read)
+    const char* tw_env = getenv("FD_TAIL_WINO");
+    const bool tail_wino = !(tw_env && atoi(tw_env) == 0) && !pl.d->layerwise() && pl.f32 && pl.d->winograd && u.tailw_u;
+    const char* tsc_env = getenv("FD_TAIL_SC");
+    const bool sc_in_tail = u.has_sc && tail_wino && pl.d->precision == FD_PRECISION_F32 && u.tailw_w3sc &&
+                            !(tsc_env && atoi(tsc_env) == 0) && !whole_proj;
     if (u.has_sc) {
         float* s = pl.buf(NB_SC, (size_t)n * ho * wo * cout);
-        if (!pl.dry && !whole_proj) {
+        if (!pl.dry && !whole_proj && !sc_in_tail) {
             // float32, stride 1: the shortcut and conv1 as one launch (both read act)
             if (pl.f32 && pl.d->precision == FD_PRECISION_F32 && !pl.d->layerwise() && u.pair_w)
                 FD_TRY(split_conv_forward_pair(csc, c1, u.pair_w, u.pair_w_floats, static_cast<const float*>(act), n, h, w, s, t1,
@@ -614,10 +631,13 @@ static int run_unit_split(Plan& pl, const Unit& u, const char* name, const void*
             bool fused = false;
             // float32: the tail with its 3x3 in Winograd F(2x2,3x3) form (FD_TAIL_WINO=0, read at every call so that a
             // test can run both: the direct-form tail below; FD_WINOGRAD=0 keeps every layer direct as well)
-            const char* tw_env = getenv("FD_TAIL_WINO");
-            const bool tail_wino = !(tw_env && atoi(tw_env) == 0);
-            if (!pl.d->layerwise() && pl.f32 && tail_wino && pl.d->winograd && u.tailw_u)
+            if (sc_in_tail) {
+                FD_TRY(conv_tail_wino_forward(u.tailw_u, c2.bias, c3, t1, n, h, w, nullptr, o3, pl.stream, &fused,
+                                              static_cast<const float*>(act), u.tailw_w3sc));
+                FD_REQUIRE(fused, "float32 tail with the shortcut inside: the kernel refused a layer it was built for");
+            } else if (tail_wino) {
                 FD_TRY(conv_tail_wino_forward(u.tailw_u, c2.bias, c3, t1, n, h, w, res, o3, pl.stream, &fused));
+            }
             if (!fused && !pl.d->layerwise())
                 FD_TRY(conv_tail_fused_forward(c2, c3, t1, n, h, w, res, o3, pl.stream, &fused));
             if (!fused) {

@@ -60,18 +60,21 @@ def test_fused_unit_tensors_match_elementwise(monkeypatch):
         new.close()
 
 
-@pytest.mark.parametrize("tail", ["winograd", "direct"])
+@pytest.mark.parametrize("tail", ["winograd+shortcut", "winograd", "direct"])
 def test_float32_fused_tail_matches_the_separate_float32_kernels(monkeypatch, tail):
     """precision="f32": an ordinary pass runs the 3x3 + 1x1 tail of each 64-channel unit as one kernel (the tensor
     between them stays in LDS as float32) -- with the 3x3 in Winograd F(2x2,3x3) form (fd_conv_tailw.hip: transforms
     in registers, nothing of the Winograd domain in memory; the default) or, with FD_TAIL_WINO=0, as a direct
     convolution (conv_tail_fused_kernel); a layer-by-layer pass runs two direct kernels.  Same float32 products up to
     the order of summation (and, for the Winograd form, its additions-only transforms), so unit outputs agree to
-    rounding noise.  The frame sizes give stage-1 maps smaller than one 8 x 16 tile, ragged in both directions, and
-    many tiles large."""
+    rounding noise.  By default the Winograd tail of the first unit also holds that unit's shortcut convolution
+    (faster_rcnn.py:45-53: conv3 + shortcut = one 1x1 over the 64 + 64 channels of t2 and the activated input; the
+    shortcut tensor is neither written nor read); FD_TAIL_SC=0 keeps the shortcut a launch of its own.  The frame
+    sizes give stage-1 maps smaller than one 8 x 16 tile, ragged in both directions, and many tiles large."""
     from facedetection_amd import profiling
     from facedetection_amd.detection import Detector
-    monkeypatch.setenv("FD_TAIL_WINO", "1" if tail == "winograd" else "0")
+    monkeypatch.setenv("FD_TAIL_WINO", "0" if tail == "direct" else "1")
+    monkeypatch.setenv("FD_TAIL_SC", "1" if tail == "winograd+shortcut" else "0")
     lay = Detector("synthetic:0", 0, own_context=True, precision="f32")
     new = Detector("synthetic:0", 0, own_context=True, precision="f32")
     lay.keep_tensors(True)
@@ -83,8 +86,12 @@ def test_float32_fused_tail_matches_the_separate_float32_kernels(monkeypatch, ta
             lay.forward(frames)
             profiling.begin()
             new.forward(frames)
-            ran = {r["kernel"] for r in profiling.end()}
-            assert ("conv_tail_wino_f32" in ran) == (tail == "winograd") and ("conv_tail_fused_f32" in ran) == (tail == "direct"), ran
+            rows = profiling.end()
+            ran = {r["kernel"] for r in rows}
+            assert ("conv_tail_wino_f32" in ran) == (tail != "direct") and ("conv_tail_fused_f32" in ran) == (tail == "direct"), ran
+            assert ("conv_tail_wino_sc_f32" in ran) == (tail == "winograd+shortcut"), ran
+            tails = sum(r["launches"] for r in rows if r["kernel"].startswith("conv_tail_"))
+            assert tails == 3, rows
             for name in ("stage1_unit1", "stage1_unit2", "stage1_unit3"):
                 want, got = lay.tensor(name), new.tensor(name)
                 assert want.shape == got.shape
@@ -102,6 +109,7 @@ def test_paired_shortcut_and_conv1_launch_gives_the_same_bits(monkeypatch):
     in two launches, so the unit's output is the same bit for bit."""
     from facedetection_amd import profiling
     from facedetection_amd.detection import Detector
+    monkeypatch.setenv("FD_TAIL_SC", "0")       # (with the shortcut inside the tail there is no shortcut launch to pair)
     det = Detector("synthetic:0", 0, own_context=True, precision="f32")
     det.keep_tensors(True, production=True)
     rng = np.random.default_rng(5)
@@ -119,5 +127,33 @@ def test_paired_shortcut_and_conv1_launch_gives_the_same_bits(monkeypatch):
             assert launches["0"] == launches["1"] + 1, launches          # one convolution launch fewer
             for name in got["1"]:
                 assert np.array_equal(got["1"][name], got["0"][name]), (name, (b, h, w))
+    finally:
+        det.close()
+
+
+def test_shortcut_inside_the_tail_saves_a_launch_and_keeps_the_values(monkeypatch):
+    """precision="f32", first unit of the 64-channel stage: with the shortcut convolution inside the Winograd tail
+    (default) a pass has one convolution launch fewer than with FD_TAIL_SC=0, and the unit outputs agree to rounding
+    noise (the shortcut's products join conv3's accumulators instead of being added as a finished tensor)."""
+    from facedetection_amd import profiling
+    from facedetection_amd.detection import Detector
+    det = Detector("synthetic:0", 0, own_context=True, precision="f32")
+    det.keep_tensors(True, production=True)
+    rng = np.random.default_rng(6)
+    try:
+        for (b, h, w) in [(2, 1080, 1920), (1, 333, 517)]:
+            frames = rng.integers(0, 256, size=(b, h, w, 3), dtype=np.uint8)
+            got, launches = {}, {}
+            for sc in ("1", "0"):
+                monkeypatch.setenv("FD_TAIL_SC", sc)
+                profiling.begin()
+                det.forward(frames)
+                rows = {r["kernel"]: r["launches"] for r in profiling.end()}
+                launches[sc] = sum(n for k, n in rows.items() if k.startswith("conv_"))
+                got[sc] = {name: det.tensor(name).copy() for name in ("stage1_unit1", "stage1_unit3", "feat")}
+            assert launches["0"] == launches["1"] + 1, launches
+            for name in got["1"]:
+                scale = float(np.abs(got["0"][name]).max())
+                assert float(np.abs(got["1"][name] - got["0"][name]).max()) <= 4e-6 * scale, (name, (b, h, w))
     finally:
         det.close()

@@ -23,6 +23,9 @@ def layer_bytes(name, M, N, K, B):
         # staged image: 4 floats per pixel, 1080 x 1920; output: the pooled, activated 64-channel tensor
         return 16.0 * B * 1080 * 1920 + w + 4.0 * (M / 4) * 64
     if name.endswith("_tail"):
+        if K > 640:
+            # the projection unit: t1 and the activated input (64 channels each), output; no residual tensor
+            return 4.0 * M * 128 + 4.0 * M * N + 4.0 * 64 * (576 + 2 * N)
         # t1 (64 channels), residual and output (256 channels); weights of both convolutions
         return 4.0 * M * 64 + 2 * 4.0 * M * N + 4.0 * 64 * (576 + N)
     if name.endswith("_sc+c1"):
