@@ -62,11 +62,12 @@ int conv_tail_fused_forward(const SplitConvParams& conv2, const SplitConvParams&
 // weights written by tail_wino_pack (host: OIHW 64 x 64 x 3 x 3 weights times out_scale[o] -> 16 x 2 x 64 x 32 floats in the kernel's reading order),
 // bias2 = the 3x3's bias; *taken as above.  With sc_act and w3_sc (and residual == NULL) the projection shortcut of
 // the unit runs inside the 1x1: sc_act = the unit's activated input [B][H][W][64], w3_sc = [cout][128] floats, row o =
-// conv3's 64 weights then the shortcut's 64 -- the shortcut tensor is neither written nor read.
+// conv3's 64 weights then the shortcut's 64 -- the shortcut tensor is neither written nor read.  With conv1 as well
+// (the unit's 64 -> 64 1x1 with ReLU, float32 form) the kernel computes t1 itself on the input patch and t1 may be NULL.
 int tail_wino_pack(const float* w_oihw, const float* out_scale, std::vector<float>* packed);
 int conv_tail_wino_forward(const float* u_wino, const float* bias2, const SplitConvParams& conv3, const float* t1, int batch,
                            int h, int w, const float* residual, const SplitConvOut& out, hipStream_t stream, bool* taken,
-                           const float* sc_act = nullptr, const float* w3_sc = nullptr);
+                           const float* sc_act = nullptr, const float* w3_sc = nullptr, const SplitConvParams* conv1 = nullptr);
 
 // A whole identity-shortcut unit of the 64-channel stage (conv1 on the float32 input through
 // BatchNorm+ReLU, conv2, conv3 + the input as residual) in one kernel; *taken as above.

@@ -27,6 +27,10 @@
 // SC (the stride-1 projection unit, the first of the stage): y = conv1x1(t2) + conv1x1_sc(act) is ONE 1x1 over the 128
 // channels [t2 | act] with the weight rows [W3 | Wsc]; the shortcut tensor (2.1 GB per 16 frames at 1080p) is neither
 // written by a launch of its own nor read back as a residual.  933 + 1 500 us -> 2 003 us for the unit, +1.8 % frames/s.
+// MODE 2 (the default for that unit): conv1 too -- the input patch in LDS is the unit's activated input, and each wave
+// turns three 16-row blocks of it into t1 in place (192 MFMAs per wave, conv1's weights as register fragments) before
+// the GEMM phase; the halo rows are computed by every tile that needs them (1.5 x conv1's FLOPs, 2 % of the unit's).
+// The whole unit is one launch and t1 is not in memory either: 263 + 2 003 -> 2 185 us.
 // F(2x2, 3x3)'s transforms are additions and halvings only: against float64 its error is the direct form's
 // (fd_winograd.hip).  Results differ from conv_tail_fused_kernel's in the last bits.
 #include "fd_conv_split_dev.h"
@@ -43,12 +47,18 @@ struct TailWinoArgs {
     SplitKArgs c;          // the 1x1: w, bias, res, y32, ysplit, post_scale / post_shift, Cout, M, w_inv_scale
     int H, W, tiles_x, tiles_y;
     unsigned x_bytes, u_bytes, w3_bytes;
-    const float* act;      // SC: the unit's activated input [B][H][W][64], the projection shortcut's operand
+    const float* act;      // MODE >= 1: the unit's activated input [B][H][W][64], the projection shortcut's operand
+    const float* w1;       // MODE 2: conv1's weights [64][64] (BatchNorm folded), bias [64] and output scale
+    const float* bias1;
+    float w1_inv_scale;
 };
 
-template <bool SC>
+// MODE 0: the tail; 1: with the projection shortcut inside the 1x1; 2: the whole projection unit -- conv1 as well,
+// computed on the input patch in LDS, so t1 never exists in memory either.
+template <int MODE>
 __global__ __launch_bounds__(256, 2) void conv_tail_wino_kernel(TailWinoArgs k) {
 #if defined(__HIP_DEVICE_COMPILE__)
+    constexpr bool SC = MODE >= 1, C1 = MODE == 2;
     constexpr int BM = 128, BN = 64, MID = 64;
     using T = SplitTile<BM, BN>;
     using E = SplitEpi<BM, BN>;
@@ -79,7 +89,7 @@ __global__ __launch_bounds__(256, 2) void conv_tail_wino_kernel(TailWinoArgs k) 
     const int tyi = trem / k.tiles_x, txi = trem - tyi * k.tiles_x;
     const int y0 = tyi * 8, x0 = txi * 16;
 
-    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)k.x, 0, k.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)(C1 ? k.act : k.x), 0, k.x_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t ur = __builtin_amdgcn_make_buffer_rsrc((void*)k.u, 0, k.u_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t w3r = __builtin_amdgcn_make_buffer_rsrc((void*)c.w, 0, k.w3_bytes, 0x00020000);
     constexpr unsigned OOB = 0x80000000u;
@@ -102,6 +112,20 @@ __global__ __launch_bounds__(256, 2) void conv_tail_wino_kernel(TailWinoArgs k) 
                                                  16, vo, 0, 0, 0);
     }
 
+    // MODE 2: conv1's weights as this lane's B fragments, [K-step][part][16-channel block], straight from memory
+    f32x4 w1f[C1 ? 2 : 1][2][C1 ? 4 : 1];
+    if constexpr (C1) {
+        const __amdgpu_buffer_rsrc_t w1r = __builtin_amdgcn_make_buffer_rsrc((void*)k.w1, 0, 64 * 64 * 4, 0x00020000);
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int part = 0; part < 2; ++part)
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni)
+                    w1f[kk][part][ni] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                        w1r, (unsigned)(((ni * 16 + frow) * MID + kk * 32 + (part * 4 + fh) * 4) * 4), 0, 0));
+    }
+
     // ---- transformed weights: step s = (i, h, j) multiplies by GEMM xi = 4 i + j, K half h.  A lane's four fragments of
     // a step (part pl, 16-channel block ni: f = 2 pl + ni) come straight from memory (L2) into registers, 16 bytes each,
     // in the packed order [s][wn][f][lane] -- every load instruction reads 1 KB of consecutive bytes -- and are requested
@@ -120,6 +144,54 @@ __global__ __launch_bounds__(256, 2) void conv_tail_wino_kernel(TailWinoArgs k) 
     __builtin_amdgcn_sched_barrier(0);
     wait_vmcnt<(PD - 1) * 4>();        // the input patch has landed (the weights requested after it may fly)
     __syncthreads();
+
+    if constexpr (C1) {
+        // ---- conv1 in place: the patch holds the unit's activated input; every wave turns three 16-row blocks of it
+        // into t1 = relu(act W1^T + b1) -- the rows of a block are read (into fragments) and written by that wave
+        // alone, and a wave's LDS operations execute in order.  Pixels outside the picture are the 3x3's zero padding:
+        // they are written as zeros, not as relu(b1).
+        float b1[4];
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) b1[ni] = k.bias1 ? k.bias1[ni * 16 + frow] : 0.f;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int rb = wave * 3 + j;
+            const int R = rb * 16 + frow;
+            f32x4 a1[2][2];
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                for (int part = 0; part < 2; ++part)
+                    a1[kk][part] = *reinterpret_cast<const f32x4*>(sbytes + kk * PLANE + R * 128 + (((part * 4 + fh) ^ ((R >> 1) & 7)) << 4));
+            f32x4 acc1[4];
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) acc1[ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                for (int part = 0; part < 2; ++part)
+#pragma unroll
+                    for (int t = 0; t < 4; ++t)
+#pragma unroll
+                        for (int ni = 0; ni < 4; ++ni)
+                            acc1[ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[kk][part][t], w1f[kk][part][ni][t], acc1[ni], 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = rb * 16 + fh * 4 + r;
+                const int py = row / PW, px = row - py * PW;
+                const int gy = y0 - 1 + py, gx = x0 - 1 + px;
+                const bool ok = row < PPIX && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni) {
+                    const float v = ok ? fmaxf(acc1[ni][r] * k.w1_inv_scale + b1[ni], 0.f) : 0.f;
+                    const int c32 = (ni & 1) * 16 + frow;
+                    *reinterpret_cast<float*>(sbytes + (ni >> 1) * PLANE + row * 128 + (((c32 >> 2) ^ ((row >> 1) & 7)) << 4) +
+                                              (c32 & 3) * 4) = v;
+                }
+            }
+        }
+        __syncthreads();
+    }
 
     // ---- phase 1: the 16 GEMMs, transform row i outermost; wave (wm, wn) owns 16 patches x 32 output channels
     // this lane's patch in the MFMA's row operand: block wm holds patch rows 2 wm, 2 wm + 1 (8 patches each)
@@ -332,7 +404,7 @@ int tail_wino_pack(const float* w_oihw, const float* out_scale, std::vector<floa
 
 int conv_tail_wino_forward(const float* u_wino, const float* bias2, const SplitConvParams& p3, const float* t1, int batch, int h,
                            int w, const float* residual, const SplitConvOut& out, hipStream_t stream, bool* taken,
-                           const float* sc_act, const float* w3_sc) {
+                           const float* sc_act, const float* w3_sc, const SplitConvParams* conv1) {
     *taken = false;
     const ConvShape& s3 = p3.s;
     const bool sc = sc_act && w3_sc;      // the projection shortcut inside the 1x1 (no residual tensor then)
@@ -342,12 +414,18 @@ int conv_tail_wino_forward(const float* u_wino, const float* bias2, const SplitC
     const long long m_ll = (long long)batch * h * w;
     const size_t x_bytes = (size_t)m_ll * 64 * 4, w3_bytes = s3.packed_floats() * 4 * (sc ? 2 : 1);
     if (x_bytes >= (1ull << 31) || m_ll >= (1ll << 29)) return FD_OK;
-    FD_REQUIRE(t1 && p3.w && (out.y32 || out.ysplit), "Winograd tail: NULL tensor");
+    FD_REQUIRE((t1 || (sc && conv1)) && p3.w && (out.y32 || out.ysplit), "Winograd tail: NULL tensor");
     TailWinoArgs k;
     k.x = t1; k.u = u_wino; k.bias2 = bias2;
     SplitKArgs& c = k.c;
     c.x = nullptr; c.w = static_cast<const uint8_t*>(sc ? (const void*)w3_sc : p3.w); c.bias = p3.bias; c.res = residual; c.y32 = out.y32;
     k.act = sc ? sc_act : nullptr;
+    // the whole projection unit: conv1 (64 -> 64, 1x1, ReLU) on the input patch inside the kernel; t1 is not read then
+    const bool c1 = sc && conv1 && conv1->f32 && conv1->w && conv1->relu && conv1->s.cin == 64 && conv1->s.cout == 64 &&
+                    conv1->s.kh == 1 && conv1->s.kw == 1 && conv1->s.stride == 1 && conv1->s.pad == 0;
+    k.w1 = c1 ? static_cast<const float*>(conv1->w) : nullptr;
+    k.bias1 = c1 ? conv1->bias : nullptr;
+    k.w1_inv_scale = c1 ? conv1->w_inv_scale : 1.f;
     c.ysplit = static_cast<uint8_t*>(out.ysplit); c.post_scale = out.post_scale; c.post_shift = out.post_shift;
     c.pre_scale = c.pre_shift = nullptr; c.w_inv_scale = p3.w_inv_scale;
     c.H = h; c.W = w; c.Cin = 64; c.Ho = h; c.Wo = w; c.Cout = s3.cout; c.KW = 1; c.stride = 1; c.pad = 0; c.K = 64;
@@ -357,12 +435,14 @@ int conv_tail_wino_forward(const float* u_wino, const float* bias2, const SplitC
     k.x_bytes = (unsigned)x_bytes; k.u_bytes = 16u * 2u * 64u * 32u * 4u; k.w3_bytes = (unsigned)w3_bytes;
     // FLOPs executed: 16 GEMMs of (patches x 64 x 64) + the 1x1
     const double patches = (double)batch * k.tiles_x * k.tiles_y * 32.0;
-    ProfScope scope(stream, sc ? "conv_tail_wino_sc_f32" : "conv_tail_wino_f32",
-                    2.0 * 16.0 * patches * 64.0 * 64.0 + 2.0 * m_ll * (double)s3.cout * (sc ? 128.0 : 64.0),
+    ProfScope scope(stream, c1 ? "unit_proj_wino_f32" : sc ? "conv_tail_wino_sc_f32" : "conv_tail_wino_f32",
+                    2.0 * 16.0 * patches * 64.0 * 64.0 + 2.0 * m_ll * (double)s3.cout * (sc ? 128.0 : 64.0) +
+                        (c1 ? 2.0 * (patches / 32.0) * 192.0 * 64.0 * 64.0 : 0.0),
                     4.0 * 64.0 * m_ll * (sc ? 2.0 : 1.0) + 4.0 * 64.0 * (16.0 * 64.0 + s3.cout * (sc ? 2.0 : 1.0)) +
                         4.0 * m_ll * s3.cout * ((sc ? 0.0 : 1.0) + (c.y32 ? 1.0 : 0.0) + (c.ysplit ? 1.0 : 0.0)));
-    if (sc) hipLaunchKernelGGL(conv_tail_wino_kernel<true>, dim3(batch * k.tiles_x * k.tiles_y), dim3(256), 0, stream, k);
-    else hipLaunchKernelGGL(conv_tail_wino_kernel<false>, dim3(batch * k.tiles_x * k.tiles_y), dim3(256), 0, stream, k);
+    if (c1) hipLaunchKernelGGL(conv_tail_wino_kernel<2>, dim3(batch * k.tiles_x * k.tiles_y), dim3(256), 0, stream, k);
+    else if (sc) hipLaunchKernelGGL(conv_tail_wino_kernel<1>, dim3(batch * k.tiles_x * k.tiles_y), dim3(256), 0, stream, k);
+    else hipLaunchKernelGGL(conv_tail_wino_kernel<0>, dim3(batch * k.tiles_x * k.tiles_y), dim3(256), 0, stream, k);
     FD_LAUNCH_CHECK();
     *taken = true;
     return FD_OK;

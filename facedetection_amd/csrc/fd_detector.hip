@@ -592,6 +592,10 @@ static int run_unit_split(Plan& pl, const Unit& u, const char* name, const void*
     const char* tsc_env = getenv("FD_TAIL_SC");
     const bool sc_in_tail = u.has_sc && tail_wino && pl.d->precision == FD_PRECISION_F32 && u.tailw_w3sc &&
                             !(tsc_env && atoi(tsc_env) == 0) && !whole_proj;
+    // ... and conv1 as well, on the input patch in LDS: the whole unit is one launch and t1 does not exist
+    // (FD_TAIL_C1=0, read at every call: conv1 as a launch of its own)
+    const char* tc1_env = getenv("FD_TAIL_C1");
+    const bool c1_in_tail = sc_in_tail && !(tc1_env && atoi(tc1_env) == 0) && c1.f32 && c1.s.cin == 64 && c1.s.cout == 64;
     if (u.has_sc) {
         float* s = pl.buf(NB_SC, (size_t)n * ho * wo * cout);
         if (!pl.dry && !whole_proj && !sc_in_tail) {
@@ -623,7 +627,7 @@ static int run_unit_split(Plan& pl, const Unit& u, const char* name, const void*
                                       pl.stream, &whole));
         if (!whole) {
             if (u.has_sc) {
-                if (!pair_done) FD_TRY(split_conv_forward(c1, act, n, h, w, nullptr, o1, pl.stream));
+                if (!pair_done && !c1_in_tail) FD_TRY(split_conv_forward(c1, act, n, h, w, nullptr, o1, pl.stream));
             } else {
                 FD_TRY(split_conv_forward_f32(c1, xraw, u.bn1_scale, u.bn1_shift, n, h, w, nullptr, o1,
                                               pl.stream));
@@ -633,7 +637,7 @@ static int run_unit_split(Plan& pl, const Unit& u, const char* name, const void*
             // test can run both: the direct-form tail below; FD_WINOGRAD=0 keeps every layer direct as well)
             if (sc_in_tail) {
                 FD_TRY(conv_tail_wino_forward(u.tailw_u, c2.bias, c3, t1, n, h, w, nullptr, o3, pl.stream, &fused,
-                                              static_cast<const float*>(act), u.tailw_w3sc));
+                                              static_cast<const float*>(act), u.tailw_w3sc, c1_in_tail ? &c1 : nullptr));
                 FD_REQUIRE(fused, "float32 tail with the shortcut inside: the kernel refused a layer it was built for");
             } else if (tail_wino) {
                 FD_TRY(conv_tail_wino_forward(u.tailw_u, c2.bias, c3, t1, n, h, w, res, o3, pl.stream, &fused));

@@ -60,7 +60,7 @@ def test_fused_unit_tensors_match_elementwise(monkeypatch):
         new.close()
 
 
-@pytest.mark.parametrize("tail", ["winograd+shortcut", "winograd", "direct"])
+@pytest.mark.parametrize("tail", ["winograd+unit", "winograd+shortcut", "winograd", "direct"])
 def test_float32_fused_tail_matches_the_separate_float32_kernels(monkeypatch, tail):
     """precision="f32": an ordinary pass runs the 3x3 + 1x1 tail of each 64-channel unit as one kernel (the tensor
     between them stays in LDS as float32) -- with the 3x3 in Winograd F(2x2,3x3) form (fd_conv_tailw.hip: transforms
@@ -69,12 +69,14 @@ def test_float32_fused_tail_matches_the_separate_float32_kernels(monkeypatch, ta
     the order of summation (and, for the Winograd form, its additions-only transforms), so unit outputs agree to
     rounding noise.  By default the Winograd tail of the first unit also holds that unit's shortcut convolution
     (faster_rcnn.py:45-53: conv3 + shortcut = one 1x1 over the 64 + 64 channels of t2 and the activated input; the
-    shortcut tensor is neither written nor read); FD_TAIL_SC=0 keeps the shortcut a launch of its own.  The frame
+    shortcut tensor is neither written nor read) and its conv1, computed on the input patch in LDS (the whole unit is
+    one launch); FD_TAIL_C1=0 keeps conv1, FD_TAIL_SC=0 the shortcut as well, a launch of its own.  The frame
     sizes give stage-1 maps smaller than one 8 x 16 tile, ragged in both directions, and many tiles large."""
     from facedetection_amd import profiling
     from facedetection_amd.detection import Detector
     monkeypatch.setenv("FD_TAIL_WINO", "0" if tail == "direct" else "1")
-    monkeypatch.setenv("FD_TAIL_SC", "1" if tail == "winograd+shortcut" else "0")
+    monkeypatch.setenv("FD_TAIL_SC", "1" if tail in ("winograd+shortcut", "winograd+unit") else "0")
+    monkeypatch.setenv("FD_TAIL_C1", "1" if tail == "winograd+unit" else "0")
     lay = Detector("synthetic:0", 0, own_context=True, precision="f32")
     new = Detector("synthetic:0", 0, own_context=True, precision="f32")
     lay.keep_tensors(True)
@@ -90,7 +92,8 @@ def test_float32_fused_tail_matches_the_separate_float32_kernels(monkeypatch, ta
             ran = {r["kernel"] for r in rows}
             assert ("conv_tail_wino_f32" in ran) == (tail != "direct") and ("conv_tail_fused_f32" in ran) == (tail == "direct"), ran
             assert ("conv_tail_wino_sc_f32" in ran) == (tail == "winograd+shortcut"), ran
-            tails = sum(r["launches"] for r in rows if r["kernel"].startswith("conv_tail_"))
+            assert ("unit_proj_wino_f32" in ran) == (tail == "winograd+unit"), ran
+            tails = sum(r["launches"] for r in rows if r["kernel"].startswith(("conv_tail_", "unit_proj_wino")))
             assert tails == 3, rows
             for name in ("stage1_unit1", "stage1_unit2", "stage1_unit3"):
                 want, got = lay.tensor(name), new.tensor(name)
@@ -131,29 +134,32 @@ def test_paired_shortcut_and_conv1_launch_gives_the_same_bits(monkeypatch):
         det.close()
 
 
-def test_shortcut_inside_the_tail_saves_a_launch_and_keeps_the_values(monkeypatch):
-    """precision="f32", first unit of the 64-channel stage: with the shortcut convolution inside the Winograd tail
-    (default) a pass has one convolution launch fewer than with FD_TAIL_SC=0, and the unit outputs agree to rounding
-    noise (the shortcut's products join conv3's accumulators instead of being added as a finished tensor)."""
+def test_shortcut_and_conv1_inside_the_tail_save_launches_and_keep_the_values(monkeypatch):
+    """precision="f32", first unit of the 64-channel stage: with the shortcut convolution inside the Winograd tail a
+    pass has one convolution launch fewer than with FD_TAIL_SC=0, with conv1 inside as well (default) two fewer, and
+    the unit outputs agree to rounding noise (the shortcut's products join conv3's accumulators instead of being added
+    as a finished tensor; conv1's values are the same products, formed in the kernel)."""
     from facedetection_amd import profiling
     from facedetection_amd.detection import Detector
     det = Detector("synthetic:0", 0, own_context=True, precision="f32")
     det.keep_tensors(True, production=True)
     rng = np.random.default_rng(6)
     try:
-        for (b, h, w) in [(2, 1080, 1920), (1, 333, 517)]:
+        for (b, h, w) in [(2, 1080, 1920), (1, 333, 517), (1, 37, 41)]:
             frames = rng.integers(0, 256, size=(b, h, w, 3), dtype=np.uint8)
             got, launches = {}, {}
-            for sc in ("1", "0"):
-                monkeypatch.setenv("FD_TAIL_SC", sc)
+            for form in ("unit", "shortcut", "separate"):
+                monkeypatch.setenv("FD_TAIL_SC", "0" if form == "separate" else "1")
+                monkeypatch.setenv("FD_TAIL_C1", "1" if form == "unit" else "0")
                 profiling.begin()
                 det.forward(frames)
                 rows = {r["kernel"]: r["launches"] for r in profiling.end()}
-                launches[sc] = sum(n for k, n in rows.items() if k.startswith("conv_"))
-                got[sc] = {name: det.tensor(name).copy() for name in ("stage1_unit1", "stage1_unit3", "feat")}
-            assert launches["0"] == launches["1"] + 1, launches
-            for name in got["1"]:
-                scale = float(np.abs(got["0"][name]).max())
-                assert float(np.abs(got["1"][name] - got["0"][name]).max()) <= 4e-6 * scale, (name, (b, h, w))
+                launches[form] = sum(n for k, n in rows.items() if k.startswith(("conv_", "unit_proj_wino")))
+                got[form] = {name: det.tensor(name).copy() for name in ("stage1_unit1", "stage1_unit3", "feat")}
+            assert launches["separate"] == launches["shortcut"] + 1 == launches["unit"] + 2, launches
+            for form in ("unit", "shortcut"):
+                for name in got[form]:
+                    scale = float(np.abs(got["separate"][name]).max())
+                    assert float(np.abs(got[form][name] - got["separate"][name]).max()) <= 4e-6 * scale, (form, name, (b, h, w))
     finally:
         det.close()

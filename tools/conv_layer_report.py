@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """Per-layer convolution timing from a rocprofv3 kernel trace of bench.py.
 
-    python tools/conv_layer_report.py <kernel_trace.csv> [micro_batch] [f16x3 | f32 | f32sep | f32pair | layers] [winograd tile: 4 | 2]
-                       (f32sep: a float32 trace taken with FD_TAIL_SC=0; f32pair: with FD_TAIL_SC=0 FD_F32_PAIR=1)
+    python tools/conv_layer_report.py <kernel_trace.csv> [micro_batch] [f16x3 | f32 | f32c1 | f32sep | f32pair | layers] [winograd tile: 4 | 2]
+       (f32c1: a float32 trace taken with FD_TAIL_C1=0; f32sep: with FD_TAIL_SC=0; f32pair: with FD_TAIL_SC=0 FD_F32_PAIR=1)
 
 Takes the convolution launches of the last complete forward pass in the trace, pairs them with
 the launch list of faster_rcnn50 at 1080p (same order as the library issues them, see layer_list)
@@ -20,12 +20,14 @@ def layer_list(B, H=1080, W=1920, R=10, mode="f16x3", tile=4):
     mode "f32": fused stem, the 3x3 + 1x1 tail of each 64-channel unit is one kernel, and the stride-1 3x3
     layers from 128 channels on (256 with tile 2) and the RPN's are one batched Winograd GEMM launch each
     ((tile + 2)^2 GEMMs over the tile x tile patches: 1/4 of the direct FLOPs with tile 4, 4/9 with tile 2,
-    rows padded to whole GEMM tiles), and the stride-1 projection unit's shortcut runs inside its tail (no launch of
-    its own); mode "f32sep": "f32" with that shortcut as a launch of its own (FD_TAIL_SC=0); mode "f32pair": "f32sep"
-    with the shortcut and conv1 as one launch (FD_F32_PAIR=1); mode "layers": every layer its own launch."""
+    rows padded to whole GEMM tiles), and the stride-1 projection unit is one launch (its shortcut inside the tail's
+    1x1, its conv1 computed on the tail's input patch: 192 rows per 8 x 16 tile); mode "f32c1": "f32" with that conv1 as
+    a launch of its own (FD_TAIL_C1=0); mode "f32sep": ... and the shortcut too (FD_TAIL_SC=0); mode "f32pair":
+    "f32sep" with the shortcut and conv1 as one launch (FD_F32_PAIR=1); mode "layers": every layer its own launch."""
     pair = mode == "f32pair"
-    sc_in_tail = mode == "f32"
-    if mode in ("f32pair", "f32sep"):
+    sc_in_tail = mode in ("f32", "f32c1")
+    c1_in_tail = mode == "f32"
+    if mode in ("f32pair", "f32sep", "f32c1"):
         mode = "f32"
     layers = []
 
@@ -79,8 +81,13 @@ def layer_list(B, H=1080, W=1920, R=10, mode="f16x3", tile=4):
                     # the shortcut's 64 channels of K inside the tail's 1x1; no shortcut launch
                     tail_row = layers.pop()
                     c1_row, sc_row = layers.pop(), layers.pop()
-                    layers.append(c1_row)
-                    layers.append((tail_row[0], tail_row[1], tail_row[2], tail_row[3] + sc_row[3], tail_row[4] + sc_row[4]))
+                    if c1_in_tail:
+                        tiles = n * ((h + 7) // 8) * ((w + 15) // 16)
+                        layers.append((nm + "_unit", tail_row[1], tail_row[2], tail_row[3] + sc_row[3] + c1_row[3],
+                                       tail_row[4] + sc_row[4] + 2.0 * tiles * 192 * 64 * 64))
+                    else:
+                        layers.append(c1_row)
+                        layers.append((tail_row[0], tail_row[1], tail_row[2], tail_row[3] + sc_row[3], tail_row[4] + sc_row[4]))
                 if pair and u == 0:
                     # the stride-1 projection unit's shortcut and conv1 (same input) as one launch
                     tail_row = layers.pop()

@@ -22,6 +22,9 @@ def layer_bytes(name, M, N, K, B):
     if name == "conv0":
         # staged image: 4 floats per pixel, 1080 x 1920; output: the pooled, activated 64-channel tensor
         return 16.0 * B * 1080 * 1920 + w + 4.0 * (M / 4) * 64
+    if name.endswith("_unit") and K > 640:
+        # the whole projection unit: the activated input (64 channels; the patch and the shortcut operand), output
+        return 4.0 * M * 64 + 4.0 * M * N + 4.0 * 64 * (64 + 576 + 2 * N)
     if name.endswith("_tail"):
         if K > 640:
             # the projection unit: t1 and the activated input (64 channels each), output; no residual tensor
