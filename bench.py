@@ -499,6 +499,7 @@ def main():
                 dist.init_process_group(backend="gloo", rank=rank, world_size=world)
                 dist.barrier()
             else:
+                torch.cuda.set_device(local)        # every collective of this rank runs on its own GPU from the first one on
                 dist.init_process_group(backend="nccl", rank=rank, world_size=world,
                                         device_id=torch.device("cuda", local))
                 dist.barrier()
