@@ -37,6 +37,14 @@ int pack_conv_weights_split(const float* w_oihw, int cin_w, const ConvShape& s, 
 int split_conv_forward(const SplitConvParams& p, const void* x_split, int batch, int h, int w, const float* residual,
                        const SplitConvOut& out, hipStream_t stream);
 
+// A bottleneck unit's last 1x1 convolution and its projection shortcut as ONE float32 GEMM (direct-to-LDS kernel with
+// two-source rows): y[m] = [x1[m] | x2[pixel (ho * stride2, wo * stride2)]] . w_cat[o], w_cat = [cout][conv3.cin + cin2]
+// floats (conv3's row, then the shortcut's).  The shortcut tensor is neither written nor read back as a residual.
+// *taken = false (and nothing launched) when the layer is outside what the kernel addresses.
+int split_conv_forward_two(const SplitConvParams& conv3, const float* w_cat, const float* x1, int batch, int ho, int wo,
+                           const float* x2, int h2, int w2, int cin2, int stride2, const SplitConvOut& out, hipStream_t stream,
+                           bool* taken);
+
 // Two 1x1 / stride-1 float32 convolutions of the same input in one launch (a projection unit's shortcut and its first
 // convolution): w_pair = pa's packed weight rows (pa.s.cout of them, a multiple of 64) followed by 64 rows of pb's
 // (pb.s.cout <= 64 real rows, the rest zero).  ya [M][pa.s.cout] gets pa's result (pa.bias / pa.relu), yb [M][pb.s.cout]

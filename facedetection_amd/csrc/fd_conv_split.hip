@@ -307,9 +307,13 @@ __global__ __launch_bounds__(256, 2) void conv_split_kernel(SplitKArgs a) {
 // (scale and shift of all K channels sit in LDS behind the pipeline stages); the loads stay direct-to-LDS with
 // counted waits, where the register-staged kernel below drains its loads at every K-step.  The activated values and
 // the order of the products are those of the register-staged kernel, so both give the same bits.
-template <int BM, int BN, int NS, int WAVES, bool F32, int OCC, bool B3, int PREK>
+// TWO (float32, 1x1): the K channels of a row come from two tensors, x (row m, Cin channels) and x2 (a strided pixel,
+// Cin2 channels) -- a bottleneck unit's last convolution and its projection shortcut as one GEMM over [t2 | act] with the
+// weight rows [W3 | Wsc], so the shortcut tensor is neither written nor read back as a residual.
+template <int BM, int BN, int NS, int WAVES, bool F32, int OCC, bool B3, int PREK, bool TWO = false>
 __device__ __forceinline__ void conv_split_glds_body(const SplitKArgs& a, unsigned x_bytes, unsigned w_bytes) {
     static_assert(!B3 || F32, "bf16x3 products are formed from float32 operand images");
+    static_assert(!TWO || (F32 && !B3 && PREK == 0), "two-source rows: float32 products only");
     static_assert(PREK == 0 || (F32 && !B3 && PREK % 32 == 0), "BatchNorm on the fragments: float32 products only");
 #if defined(__HIP_DEVICE_COMPILE__)   // buffer-resource builtins exist in device code only; the host pass needs just the stub
     constexpr int WROWS = BM / (WAVES / 2);     // rows of the tile per wave row
@@ -357,7 +361,8 @@ __device__ __forceinline__ void conv_split_glds_body(const SplitKArgs& a, unsign
     int hi0[GA], wi0[GA];
     unsigned abase[GA];                          // byte offset of the row's window origin (+ its chunk)
     bool mval[GA];
-    const bool linear_rows = a.K == a.Cin && a.stride == 1 && a.pad == 0 && a.Ho == a.H && a.Wo == a.W;
+    unsigned abase2[TWO ? GA : 1];               // TWO: the row's pixel in the second tensor (+ its chunk)
+    const bool linear_rows = TWO || (a.K == a.Cin && a.stride == 1 && a.pad == 0 && a.Ho == a.H && a.Wo == a.W);
 #pragma unroll
     for (int i = 0; i < GA; ++i) {
         const int row = (wave + WAVES * i) * 8 + lrow;              // row inside the tile
@@ -365,6 +370,14 @@ __device__ __forceinline__ void conv_split_glds_body(const SplitKArgs& a, unsign
         const int m = tile_m * BM + row;
         mval[i] = m < a.M;
         const int mm = mval[i] ? m : 0;
+        if constexpr (TWO) {
+            const int hw = a.Ho * a.Wo;
+            const int img = mm / hw;
+            const int rem = mm - img * hw;
+            const int ho = rem / a.Wo;
+            const int wo = rem - ho * a.Wo;
+            abase2[i] = (unsigned)(((img * a.H2 + ho * a.stride2) * a.W2 + wo * a.stride2) * a.Cin2 * 4 + chunk * 16);
+        }
         if (linear_rows) {
             // 1x1, stride 1: output row m reads input row m, no pixel coordinates (and no divisions) needed
             hi0[i] = 0;
@@ -397,7 +410,8 @@ __device__ __forceinline__ void conv_split_glds_body(const SplitKArgs& a, unsign
     // each, so a workgroup's working set between re-uses is a few dozen KB and stays in L2; with
     // the taps outermost every tap streamed the rows' full channel depth and a 3x3 layer fetched
     // its input nine times from memory (PMC: 612 MB for a 67 MB input).
-    const int ntaps = a.K / a.Cin, cchunks = a.Cin / SBK;
+    const int ntaps = TWO ? 1 : a.K / a.Cin, cchunks = (TWO ? a.K : a.Cin) / SBK;
+    const __amdgpu_buffer_rsrc_t xr2 = __builtin_amdgcn_make_buffer_rsrc((void*)(TWO ? a.x2 : a.x), 0, TWO ? a.x2_bytes : x_bytes, 0x00020000);
     int kh, kw, coff, tapi;
     {
         const int chunk = kb / ntaps;
@@ -424,9 +438,16 @@ __device__ __forceinline__ void conv_split_glds_body(const SplitKArgs& a, unsign
 #define FD_ISSUE(KT, STG)                                                                         \
     do {                                                                                          \
         float* sa_ = smem + (STG) * STAGE;                                                        \
-        _Pragma("unroll") for (int i = 0; i < GA; ++i)                                            \
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(                                             \
-                xr, (__attribute__((address_space(3))) void*)(sa_ + (wave + WAVES * i) * 256), 16, avo[i], coff * 4, 0, 0); \
+        if (TWO && coff >= a.Cin) {                                                               \
+            _Pragma("unroll") for (int i = 0; i < GA; ++i)                                        \
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(                                         \
+                    xr2, (__attribute__((address_space(3))) void*)(sa_ + (wave + WAVES * i) * 256), 16, \
+                    mval[i] ? abase2[TWO ? i : 0] : OOB, (coff - a.Cin) * 4, 0, 0);               \
+        } else {                                                                                  \
+            _Pragma("unroll") for (int i = 0; i < GA; ++i)                                        \
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(                                         \
+                    xr, (__attribute__((address_space(3))) void*)(sa_ + (wave + WAVES * i) * 256), 16, avo[i], coff * 4, 0, 0); \
+        }                                                                                         \
         _Pragma("unroll") for (int i = 0; i < GB; ++i)                                            \
             __builtin_amdgcn_raw_ptr_buffer_load_lds(                                             \
                 wr, (__attribute__((address_space(3))) void*)(sa_ + BM * 32 + (wave + WAVES * i) * 256), 16, \
@@ -544,6 +565,26 @@ template <int BM, int BN, int NS, int WAVES = 4, bool F32 = false, int OCC = 0, 
 __global__ __launch_bounds__(WAVES * 64, OCC ? OCC : (WAVES == 4 ? 2 : 1)) void conv_split_glds_kernel(SplitKArgs a, unsigned x_bytes,
                                                                                       unsigned w_bytes) {
     conv_split_glds_body<BM, BN, NS, WAVES, F32, OCC, B3, 0>(a, x_bytes, w_bytes);
+}
+
+// float32, two-source rows (a unit's last convolution and its projection shortcut as one GEMM)
+template <int BM, int BN, int NS>
+__global__ __launch_bounds__(256, 2) void conv_split_glds_two_kernel(SplitKArgs a, unsigned x_bytes, unsigned w_bytes) {
+    conv_split_glds_body<BM, BN, NS, 4, true, 0, false, 0, true>(a, x_bytes, w_bytes);
+}
+
+template <int BM, int BN, int NS>
+static int launch_split_glds_two(const SplitKArgs& a, size_t x_bytes, size_t w_bytes, hipStream_t stream) {
+    static const std::string name = std::string("conv_f32_") + std::to_string(BM) + "x" + std::to_string(BN) + "_two";
+    ProfScope scope(stream, name.c_str(), 2.0 * a.M * a.Cout * (double)a.K,
+                    4.0 * a.M * (double)a.K + 4.0 * a.Cout * (double)a.K +
+                        4.0 * a.M * a.Cout * ((a.res ? 1.0 : 0.0) + (a.y32 ? 1.0 : 0.0) + (a.ysplit ? 1.0 : 0.0)));
+    SplitKArgs k = a;
+    k.tiles_n = ceil_div(a.Cout, BN);
+    hipLaunchKernelGGL((conv_split_glds_two_kernel<BM, BN, NS>), dim3(ceil_div(a.M, BM) * k.tiles_n), dim3(256), 0, stream, k,
+                       (unsigned)x_bytes, (unsigned)w_bytes);
+    FD_LAUNCH_CHECK();
+    return FD_OK;
 }
 
 // float32, BatchNorm + ReLU on the activation fragments (input channels <= PREK)
@@ -1198,6 +1239,38 @@ int split_conv_forward_pair(const SplitConvParams& pa, const SplitConvParams& pb
     a.alt_relu = pb.relu;
     *taken = true;
     return launch_split_glds<128, 64, 2, 4, true, 3>(a, x_bytes, w_bytes, stream);
+}
+
+int split_conv_forward_two(const SplitConvParams& p3, const float* w_cat, const float* x1, int batch, int ho, int wo,
+                           const float* x2, int h2, int w2, int cin2, int stride2, const SplitConvOut& out, hipStream_t stream,
+                           bool* taken) {
+    *taken = false;
+    const ConvShape& s = p3.s;
+    const long long m_ll = (long long)batch * ho * wo;
+    const int k = s.cin + cin2;
+    const size_t x_bytes = (size_t)m_ll * s.cin * 4, x2_bytes = (size_t)batch * h2 * w2 * cin2 * 4, w_bytes = (size_t)s.cout * k * 4;
+    if (!p3.f32 || out.b3 || !w_cat || !x2 || s.kh != 1 || s.kw != 1 || s.stride != 1 || s.pad != 0 || s.cin % 32 || cin2 % 32 ||
+        s.cout % 8 || x_bytes >= (1ull << 31) || x2_bytes >= (1ull << 31) || w_bytes >= (1ull << 31) || m_ll >= (1ll << 29) ||
+        (ho - 1) * stride2 >= h2 || (wo - 1) * stride2 >= w2)
+        return FD_OK;
+    FD_REQUIRE(x1 && (out.y32 || out.ysplit) && batch > 0, "two-source convolution: NULL tensor");
+    SplitKArgs a;
+    a.x = reinterpret_cast<const uint8_t*>(x1);
+    a.w = reinterpret_cast<const uint8_t*>(w_cat);
+    a.bias = p3.bias; a.res = nullptr; a.y32 = out.y32; a.ysplit = static_cast<uint8_t*>(out.ysplit);
+    a.post_scale = out.post_scale; a.post_shift = out.post_shift; a.w_inv_scale = p3.w_inv_scale;
+    a.pre_scale = a.pre_shift = nullptr;
+    a.H = ho; a.W = wo; a.Cin = s.cin; a.Ho = ho; a.Wo = wo; a.Cout = s.cout; a.KW = 1; a.stride = 1; a.pad = 0; a.K = k;
+    a.M = (int)m_ll; a.relu = p3.relu; a.tiles_n = 0; a.ksplit = 1; a.kchunk = k / SBK; a.partial = nullptr; a.clamped = out.clamped;
+    a.f32 = 1;
+    a.x2 = reinterpret_cast<const uint8_t*>(x2); a.Cin2 = cin2; a.H2 = h2; a.W2 = w2; a.stride2 = stride2; a.x2_bytes = (unsigned)x2_bytes;
+    // the tile shape does not change the order in which an output element accumulates over K
+    const long long t128 = (long long)ceil_div(a.M, 128) * ceil_div(s.cout, 128);
+    const long long t12864 = (long long)ceil_div(a.M, 128) * ceil_div(s.cout, 64);
+    *taken = true;
+    if (s.cout > 64 && t128 >= 384) return launch_split_glds_two<128, 128, 2>(a, x_bytes, w_bytes, stream);
+    if (t12864 >= 384) return launch_split_glds_two<128, 64, 3>(a, x_bytes, w_bytes, stream);
+    return launch_split_glds_two<64, 64, 4>(a, x_bytes, w_bytes, stream);
 }
 
 int split_conv_forward(const SplitConvParams& p, const void* x_split, int batch, int h, int w, const float* residual,

@@ -42,6 +42,11 @@ struct SplitKArgs {
     const float* alt_bias = nullptr;
     int alt_relu = 0;
     int stream_res = 0;      // residual values of large tensors are read with streaming loads
+    // two-source 1x1 (direct-to-LDS kernel, float32): the K = Cin + Cin2 channels of an output row are row m of x
+    // (Cin channels) followed by the Cin2 channels of pixel (ho * stride2, wo * stride2) of the [.][H2][W2][Cin2] tensor x2
+    const uint8_t* x2 = nullptr;
+    int Cin2 = 0, H2 = 0, W2 = 0, stride2 = 1;
+    unsigned x2_bytes = 0;
     int f32;                 // float32 operands (1; 2: with bf16x3 products): x, w and the "split" output are plain float32 tensors (same
                              // 4 bytes per element, so the same addressing; 128-byte rows of 32 floats)
 };

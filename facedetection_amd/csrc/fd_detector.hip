@@ -27,6 +27,7 @@ struct Unit {
     WinoConvParams w_conv2;                            // conv2 in Winograd form (wide stride-1 layers only; both precisions)
     const float* tailw_u = nullptr;                    // 64-channel units: conv2's F(2x2,3x3) weights for the fused float32 tail
     const float* tailw_w3sc = nullptr;                 // ... of the stride-1 projection unit: [cout][conv3's 64 | shortcut's 64] weights
+    const float* c3sc_w = nullptr;                     // projection units of the later stages: [cout][conv3's mid | shortcut's cin] weights
     const float* pair_w = nullptr;                     // stride-1 projection units: shortcut rows + conv1 rows, one float32 GEMM
     size_t pair_w_floats = 0;
     const float *bn1_scale = nullptr, *bn1_shift = nullptr;   // the unit's input BatchNorm (device)
@@ -283,6 +284,16 @@ static int build_unit(fd_detector* d, const ParamTable& t, const std::string& na
             FD_HIP(hipMemcpy2D(pw, 128 * sizeof(float), u->f_conv3.w, 64 * sizeof(float), 64 * sizeof(float), cout, hipMemcpyDeviceToDevice));
             FD_HIP(hipMemcpy2D(pw + 64, 128 * sizeof(float), u->f_sc.w, 64 * sizeof(float), 64 * sizeof(float), cout, hipMemcpyDeviceToDevice));
             u->tailw_w3sc = pw;
+        }
+        if (mid >= 128 && mid <= 256 && u->f_sc.w && u->f_conv3.w && !u->f_sc.bias) {
+            // conv3 and the shortcut as one two-source GEMM (float32): the weight rows side by side, K = mid + cin
+            const size_t kc = (size_t)mid + cin;
+            float* pw = nullptr;
+            FD_HIP(hipMalloc((void**)&pw, (size_t)cout * kc * sizeof(float)));
+            d->owned.push_back(pw);
+            FD_HIP(hipMemcpy2D(pw, kc * sizeof(float), u->f_conv3.w, mid * sizeof(float), mid * sizeof(float), cout, hipMemcpyDeviceToDevice));
+            FD_HIP(hipMemcpy2D(pw + mid, kc * sizeof(float), u->f_sc.w, cin * sizeof(float), cin * sizeof(float), cout, hipMemcpyDeviceToDevice));
+            u->c3sc_w = pw;
         }
         if (stride == 1 && mid <= 64 && cout % 64 == 0 && u->f_sc.w && u->f_conv1.w) {
             // the shortcut and conv1 read the same tensor: their float32 weight rows in one buffer, conv1's padded to 64
@@ -591,14 +602,22 @@ static int run_unit_split(Plan& pl, const Unit& u, const char* name, const void*
     const bool tail_wino = !(tw_env && atoi(tw_env) == 0) && !pl.d->layerwise() && pl.f32 && pl.d->winograd && u.tailw_u;
     const char* tsc_env = getenv("FD_TAIL_SC");
     const bool sc_in_tail = u.has_sc && tail_wino && pl.d->precision == FD_PRECISION_F32 && u.tailw_w3sc &&
-                            !(tsc_env && atoi(tsc_env) == 0) && !whole_proj;
+                            !(tsc_env && atoi(tsc_env) == 0) && !whole_proj &&
+                            (unsigned long long)n * h * w * 64ull * 4ull < (1ull << 31);     // (the kernel's 32-bit byte offsets)
     // ... and conv1 as well, on the input patch in LDS: the whole unit is one launch and t1 does not exist
     // (FD_TAIL_C1=0, read at every call: conv1 as a launch of its own)
     const char* tc1_env = getenv("FD_TAIL_C1");
     const bool c1_in_tail = sc_in_tail && !(tc1_env && atoi(tc1_env) == 0) && c1.f32 && c1.s.cin == 64 && c1.s.cout == 64;
+    // ... of the 128- and 256-channel stages: the shortcut as cin more channels of conv3's K, a two-source GEMM
+    // (FD_SC_IN_C3=0, read at every call: the shortcut as a launch of its own and a residual read)
+    const char* sc3_env = getenv("FD_SC_IN_C3");
+    const bool sc_in_c3 = u.has_sc && u.c3sc_w && pl.f32 && pl.d->precision == FD_PRECISION_F32 && !pl.d->layerwise() &&
+                          !sc_in_tail && !whole_proj && !(sc3_env && atoi(sc3_env) == 0) &&
+                          (unsigned long long)n * h * w * u.s_sc.s.cin * 4ull < (1ull << 31) &&
+                          (unsigned long long)n * ho * wo * (unsigned long long)mid * 4ull < (1ull << 31);
     if (u.has_sc) {
         float* s = pl.buf(NB_SC, (size_t)n * ho * wo * cout);
-        if (!pl.dry && !whole_proj && !sc_in_tail) {
+        if (!pl.dry && !whole_proj && !sc_in_tail && !sc_in_c3) {
             // float32, stride 1: the shortcut and conv1 as one launch (both read act)
             if (pl.f32 && pl.d->precision == FD_PRECISION_F32 && !pl.d->layerwise() && u.pair_w)
                 FD_TRY(split_conv_forward_pair(csc, c1, u.pair_w, u.pair_w_floats, static_cast<const float*>(act), n, h, w, s, t1,
@@ -648,7 +667,13 @@ static int run_unit_split(Plan& pl, const Unit& u, const char* name, const void*
                 if (wino2) FD_TRY(wino_conv_forward(u.w_conv2, t1, n, h, w, wino_v, wino_m, t2, pl.stream, o2.b3, o2.b3_balance));
                 else if (wino2s) FD_TRY(wino_conv_forward_split(u.w_conv2, t1, n, h, w, wino_v, wino_m, t2, pl.d->clamped, pl.stream));
                 else FD_TRY(split_conv_forward(c2, t1, n, h, w, nullptr, o2, pl.stream));
-                FD_TRY(split_conv_forward(c3, t2, n, ho, wo, res, o3, pl.stream));
+                bool two = false;
+                if (sc_in_c3) {
+                    FD_TRY(split_conv_forward_two(c3, u.c3sc_w, t2, n, ho, wo, static_cast<const float*>(act), h, w, csc.s.cin,
+                                                  csc.s.stride, o3, pl.stream, &two));
+                    FD_REQUIRE(two, "two-source convolution refused a layer it was built for");
+                }
+                if (!two) FD_TRY(split_conv_forward(c3, t2, n, ho, wo, res, o3, pl.stream));
             }
         }
     }

@@ -163,3 +163,35 @@ def test_shortcut_and_conv1_inside_the_tail_save_launches_and_keep_the_values(mo
                     assert float(np.abs(got[form][name] - got["separate"][name]).max()) <= 4e-6 * scale, (form, name, (b, h, w))
     finally:
         det.close()
+
+
+def test_projection_shortcut_inside_conv3_of_the_later_stages(monkeypatch):
+    """precision="f32", first units of the 128- and 256-channel stages (stride 2; faster_rcnn.py:45-53): conv3 and the
+    projection shortcut run as ONE GEMM whose rows take their channels from two tensors -- t2's row, then the
+    activated input's pixel (2 ho, 2 wo) -- against the weight rows [W3 | Wsc]; FD_SC_IN_C3=0 runs the shortcut as a
+    launch of its own and adds its tensor as conv3's residual.  Two launches fewer per pass, unit outputs equal to
+    rounding noise; frame sizes with ragged maps and a map smaller than one tile."""
+    from facedetection_amd import profiling
+    from facedetection_amd.detection import Detector
+    det = Detector("synthetic:0", 0, own_context=True, precision="f32")
+    det.keep_tensors(True, production=True)
+    rng = np.random.default_rng(8)
+    try:
+        for (b, h, w) in [(2, 1080, 1920), (3, 333, 517), (1, 37, 41)]:
+            frames = rng.integers(0, 256, size=(b, h, w, 3), dtype=np.uint8)
+            got, launches, names = {}, {}, {}
+            for form in ("1", "0"):
+                monkeypatch.setenv("FD_SC_IN_C3", form)
+                profiling.begin()
+                det.forward(frames)
+                rows = {r["kernel"]: r["launches"] for r in profiling.end()}
+                names[form] = set(rows)
+                launches[form] = sum(n for k, n in rows.items() if k.startswith(("conv_", "unit_proj_wino")))
+                got[form] = {name: det.tensor(name).copy() for name in ("stage2_unit1", "stage2_unit4", "stage3_unit1", "feat")}
+            assert launches["0"] == launches["1"] + 2, launches
+            assert any(k.endswith("_two") for k in names["1"]) and not any(k.endswith("_two") for k in names["0"]), names
+            for name in got["1"]:
+                scale = float(np.abs(got["0"][name]).max())
+                assert float(np.abs(got["1"][name] - got["0"][name]).max()) <= 4e-6 * scale, (name, (b, h, w))
+    finally:
+        det.close()

@@ -20,10 +20,12 @@ def test_launch_list_of_the_float32_pass():
     # 354.5 GFLOP per 1080p frame when every layer is a direct convolution (10 rois into the head)
     assert direct / 16 / 1e9 == pytest.approx(354.5, rel=2e-3)
     sep, c1, unit = (rep.layer_list(16, mode=m) for m in ("f32sep", "f32c1", "f32"))
-    # shortcut inside the tail: one launch fewer; conv1 as well: two fewer
-    assert len(sep) == len(c1) + 1 == len(unit) + 2
+    # shortcut inside the tail: one launch fewer; conv1 as well, and the shortcuts of the two later projection units
+    # inside their conv3: five fewer
+    assert len(sep) == len(c1) + 1 == len(unit) + 4
     names = [l[0] for l in unit]
     assert "s1u1_unit" in names and "s1u1_sc" not in names and "s1u1_c1" not in names
+    assert "s2u1_sc" not in names and "s3u1_sc" not in names and "s4u1_sc" in names
     # the Winograd forms execute fewer FLOPs than the direct ones; the unit kernel a few more than its three layers
     assert sum(l[4] for l in sep) < 0.7 * direct
     assert sum(l[4] for l in unit) > sum(l[4] for l in sep)

@@ -2,7 +2,7 @@
 """Per-layer convolution timing from a rocprofv3 kernel trace of bench.py.
 
     python tools/conv_layer_report.py <kernel_trace.csv> [micro_batch] [f16x3 | f32 | f32c1 | f32sep | f32pair | layers] [winograd tile: 4 | 2]
-       (f32c1: a float32 trace taken with FD_TAIL_C1=0; f32sep: with FD_TAIL_SC=0; f32pair: with FD_TAIL_SC=0 FD_F32_PAIR=1)
+       (f32c1: a float32 trace taken with FD_TAIL_C1=0 FD_SC_IN_C3=0; f32sep: with FD_TAIL_SC=0 FD_SC_IN_C3=0; f32pair: ... and FD_F32_PAIR=1)
 
 Takes the convolution launches of the last complete forward pass in the trace, pairs them with
 the launch list of faster_rcnn50 at 1080p (same order as the library issues them, see layer_list)
@@ -27,6 +27,7 @@ def layer_list(B, H=1080, W=1920, R=10, mode="f16x3", tile=4):
     pair = mode == "f32pair"
     sc_in_tail = mode in ("f32", "f32c1")
     c1_in_tail = mode == "f32"
+    sc_in_c3 = mode == "f32"          # projection units of the 128- and 256-channel stages: shortcut inside conv3's GEMM
     if mode in ("f32pair", "f32sep", "f32c1"):
         mode = "f32"
     layers = []
@@ -65,6 +66,9 @@ def layer_list(B, H=1080, W=1920, R=10, mode="f16x3", tile=4):
             wino = wino or (mode == "f16x3" and tile == 4 and st == 1 and mid >= 256 and h * w > 49)
             h2, w2 = conv(nm + "_c2", n, h, w, mid, mid, 3, st, 1, wino=wino)
             conv(nm + "_c3", n, h2, w2, mid, cout, 1, 1, 0)
+            if sc_in_c3 and u == 0 and s in (1, 2):
+                c3_row, c2_row, c1_row, sc_row = layers.pop(), layers.pop(), layers.pop(), layers.pop()
+                layers.extend([c1_row, c2_row, (c3_row[0], c3_row[1], c3_row[2], c3_row[3] + sc_row[3], c3_row[4] + sc_row[4])])
             if mid == 64 and st == 1 and mode != "layers":
                 # f16x3: whole unit in one kernel (4 layers for the projection unit); f32: conv2 + conv3
                 k = 2 if mode == "f32" else (4 if u == 0 else 3)

@@ -40,6 +40,8 @@ def layer_bytes(name, M, N, K, B):
         # direct 3x3 with stride 2: every input pixel is read (4 M pixels of K / 9 channels)
         return 4.0 * (4 * M) * (K / 9) + w + 4.0 * M * N
     if kind == "c3":
+        if name in ("s2u1_c3", "s3u1_c3") and K > N // 4:
+            return 4.0 * M * K + w + 4.0 * M * N            # the projection shortcut inside: two-source rows, no residual
         return 4.0 * M * K + w + 2 * 4.0 * M * N           # + residual
     return 4.0 * M * K + w + 4.0 * M * N                    # sc (its strided rows only), c1, rpnout
 
