@@ -1049,6 +1049,9 @@ static int split_conv_dispatch(const SplitConvParams& p, const void* x_split, co
                               a.K == a.Cin;
             if (frag && s.cout > 64 && t128 >= 384 && a.K <= 1024)
                 return launch_split_glds_pre<128, 128, 2, 0, 1024>(a, x_bytes, w_bytes, stream);
+            // (K = 2048: the ROI head's layers with thousands of rois; 80 KB of LDS, still two workgroups per CU)
+            if (frag && s.cout > 64 && t128 >= 384 && a.K <= 2048)
+                return launch_split_glds_pre<128, 128, 2, 0, 2048>(a, x_bytes, w_bytes, stream);
             if (frag && t12864 >= 1536 && a.K <= 256) return launch_split_glds_pre<128, 64, 2, 3, 256>(a, x_bytes, w_bytes, stream);
             if (s.cout > 64 && t128 >= 384) return launch_split_reg<128, 128, REG_PRE, true>(a, x_bytes, w_bytes, stream);
             // a single frame's 64-channel layers (1 013 tiles of 128 x 64): 59 -> 52 us on 64 x 64 tiles; from two

@@ -21,6 +21,7 @@ CASES = [
     (1, 135, 240, 512, 128, True, True, True),      # ... 128 x 64 tiles, two workgroups per CU
     (1, 270, 480, 256, 64, True, True, False),      # ... 64 output channels on 64 x 64 tiles: register-staged kernel
     (10, 7, 7, 2048, 512, True, True, True),        # the ROI head's layer (K unsplit through this entry point)
+    (300, 14, 14, 2048, 512, True, True, True),     # the ROI head's layer with many rois: 128 x 128 tiles, K = 2048
     (2, 14, 14, 4096, 512, True, True, False),      # more channels than the fragment kernel keeps in LDS
 ]
 
