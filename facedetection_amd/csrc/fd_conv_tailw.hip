@@ -11,9 +11,10 @@
 //     the fragments of the four transform columns j -- two LDS reads and four additions per fragment;
 //   * the 16 GEMMs M[i][j] = V[i][j] U[i][j]^T (32 patches x 64 channels x K = 64 each): wave (wm, wn) owns 16
 //     patches x 32 output channels of ALL of them, transform row i outermost, so only the four GEMMs of one row are
-//     live as accumulators (32 registers).  The transformed weights never touch LDS: a lane's fragments of a step
-//     (GEMM, K half) are 4 x 16 bytes that it reads straight from L2 into registers three steps ahead, from a copy
-//     packed in reading order (every load instruction fetches 1 KB of consecutive bytes) -- phase 1 has no barrier;
+//     live as accumulators (32 registers).  The transformed weights never touch LDS: a lane's fragments of a
+//     sub-step (GEMM, K half, 16-channel part: 8 MFMAs) are 2 x 16 bytes that it reads straight from L2 into registers
+//     five sub-steps ahead, from a copy packed in reading order (every load instruction fetches 1 KB of consecutive
+//     bytes) -- phase 1 has no barrier; the activation fragments are formed one 16-channel part at a time (16 registers);
 //   * the output transform Y = A^T M A is linear in M: after each transform row the wave folds that row's column
 //     combination into its four output pixels per patch (32 registers), entirely in registers; bias + ReLU, and t2
 //     lands in LDS as the A operand of the 1x1, which then runs exactly as in conv_tail_fused_kernel (64 output
@@ -65,11 +66,20 @@ __global__ __launch_bounds__(256, 2) void conv_tail_wino_kernel(TailWinoArgs k) 
     constexpr int PW = 18, PPIX = 180, PROWS = 192;
     constexpr int PLANE = PROWS * 128;                  // bytes per K-half plane of the input patch
     constexpr int D_BYTES = 2 * PLANE;                  // 48 KB
-    constexpr int A_OFF = D_BYTES;                      // t2 as the 1x1's A operand: 2 K-steps x 128 rows x 128 B
-    constexpr int SMEM_BYTES = A_OFF + (MID / 32) * BM * 128;   // 80 KB
+    // t2 behind the patch: 80 KB, two workgroups per CU.  O3 (MODE 0 only; with __launch_bounds__(256, 3)): t2 laid
+    // over the input patch once every wave is done with it, the 1x1's staging / weight chunk behind it -- 52 KB, three
+    // workgroups per CU at 168 registers (13 float4 values of the output transform spilled across the GEMM phase).
+    // Measured: 1 621 / 1 761 us per unit against 1 484 / 1 612 us with two workgroups -- the third workgroup costs
+    // more in contention than it covers -- so it stays off.
+    constexpr bool O3 = false;
     constexpr int KK3 = SC ? 4 : 2;                     // K-steps of the 1x1: t2's 64 channels (+ the shortcut operand's 64)
-    constexpr int CS_BYTES = SC ? 32 * 1024 : 20 * 1024; // epilogue staging / weight chunk of the 1x1, at offset 0
-    static_assert(SMEM_BYTES == 80 * 1024 && T::EPI * 4 <= CS_BYTES && KK3 * 64 * 128 <= CS_BYTES && CS_BYTES <= A_OFF, "LDS plan");
+    constexpr int CS_BYTES = SC ? 32 * 1024 : 20 * 1024; // epilogue staging / weight chunk of the 1x1
+    constexpr int A_BYTES = (MID / 32) * BM * 128;      // t2 as the 1x1's A operand: 2 K-steps x 128 rows x 128 B
+    constexpr int A_OFF = O3 ? 0 : D_BYTES;
+    constexpr int CS_OFF = O3 ? A_BYTES : 0;
+    constexpr int SMEM_BYTES = O3 ? A_BYTES + CS_BYTES : D_BYTES + A_BYTES;
+    static_assert(SMEM_BYTES >= D_BYTES && T::EPI * 4 <= CS_BYTES && KK3 * 64 * 128 <= CS_BYTES &&
+                      (O3 ? 3 * SMEM_BYTES <= 160 * 1024 : (SMEM_BYTES == 80 * 1024 && CS_BYTES <= A_OFF)), "LDS plan");
     __shared__ __attribute__((aligned(16))) float smem[SMEM_BYTES / 4];
     char* const sbytes = reinterpret_cast<char*>(smem);
 
@@ -130,19 +140,22 @@ __global__ __launch_bounds__(256, 2) void conv_tail_wino_kernel(TailWinoArgs k) 
     // a step (part pl, 16-channel block ni: f = 2 pl + ni) come straight from memory (L2) into registers, 16 bytes each,
     // in the packed order [s][wn][f][lane] -- every load instruction reads 1 KB of consecutive bytes -- and are requested
     // PD - 1 steps ahead, so phase 1 has no LDS traffic for the weights and no barrier.
-    constexpr int PD = 4;
-    f32x4 bq[PD][4];
+    // Sub-step u = (i, h, pl, j): 8 MFMAs on the two fragments f = 2 pl + ni of step s = (i, h, j), requested PD - 1
+    // sub-steps ahead.
+    constexpr int PD = 6;
+    f32x4 bq[PD][2];
     const unsigned blane = (unsigned)(lane * 16);
-#define FD_ULOAD(S)                                                                               \
+#define FD_ULOAD(U)                                                                               \
     do {                                                                                          \
-        _Pragma("unroll") for (int f = 0; f < 4; ++f)                                             \
-            bq[(S) % PD][f] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(    \
-                ur, blane + f * 1024, ((S) * 2 + wn) * 4096, 0));                                 \
+        const int s_ = ((U) >> 3) * 4 + ((U) & 3), pl_ = ((U) >> 2) & 1;                          \
+        _Pragma("unroll") for (int ni = 0; ni < 2; ++ni)                                          \
+            bq[(U) % PD][ni] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(   \
+                ur, blane + (pl_ * 2 + ni) * 1024, (s_ * 2 + wn) * 4096, 0));                     \
     } while (0)
 #pragma unroll
     for (int st = 0; st < PD - 1; ++st) FD_ULOAD(st);
     __builtin_amdgcn_sched_barrier(0);
-    wait_vmcnt<(PD - 1) * 4>();        // the input patch has landed (the weights requested after it may fly)
+    wait_vmcnt<(PD - 1) * 2>();        // the input patch has landed (the weights requested after it may fly)
     __syncthreads();
 
     if constexpr (C1) {
@@ -211,12 +224,11 @@ __global__ __launch_bounds__(256, 2) void conv_tail_wino_kernel(TailWinoArgs k) 
             for (int ni = 0; ni < 2; ++ni) acc[j][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-            // activation fragments of this (i, K half): [part][j]
-            f32x4 av[2][4];
+            // one 16-channel part at a time: its activation fragments [j], then the four column GEMMs' MFMAs
 #pragma unroll
             for (int pl = 0; pl < 2; ++pl) {
                 const int cq = pl * 4 + fh;
-                f32x4 rr[4];
+                f32x4 rr[4], av[4];
 #pragma unroll
                 for (int b = 0; b < 4; ++b) {
                     const int ra = r00 + a1 * PW + b, rb = r00 + a2 * PW + b;
@@ -224,24 +236,22 @@ __global__ __launch_bounds__(256, 2) void conv_tail_wino_kernel(TailWinoArgs k) 
                     const f32x4 d2 = *reinterpret_cast<const f32x4*>(sbytes + h * PLANE + rb * 128 + ((cq ^ ((rb >> 1) & 7)) << 4));
                     rr[b] = d1 + s2 * d2;
                 }
-                av[pl][0] = rr[0] - rr[2];
-                av[pl][1] = rr[1] + rr[2];
-                av[pl][2] = rr[2] - rr[1];
-                av[pl][3] = rr[1] - rr[3];
-            }
+                av[0] = rr[0] - rr[2];
+                av[1] = rr[1] + rr[2];
+                av[2] = rr[2] - rr[1];
+                av[3] = rr[1] - rr[3];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int s = (i_ * 2 + h) * 4 + j;
-                if (s + PD - 1 < 32) FD_ULOAD(s + PD - 1);
-                __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-                for (int pl = 0; pl < 2; ++pl)
+                for (int j = 0; j < 4; ++j) {
+                    const int u = ((i_ * 2 + h) * 2 + pl) * 4 + j;
+                    if (u + PD - 1 < 64) FD_ULOAD(u + PD - 1);
+                    __builtin_amdgcn_s_setprio(1);
 #pragma unroll
                     for (int t = 0; t < 4; ++t)
 #pragma unroll
                         for (int ni = 0; ni < 2; ++ni)
-                            acc[j][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[pl][j][t], bq[s % PD][pl * 2 + ni][t], acc[j][ni], 0, 0, 0);
-                __builtin_amdgcn_s_setprio(0);
+                            acc[j][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j][t], bq[u % PD][ni][t], acc[j][ni], 0, 0, 0);
+                    __builtin_amdgcn_s_setprio(0);
+                }
             }
         }
         // this row's share of the output transform: T[i][q] over the columns j, then Y[p][q] += A^T[p][i] T[i][q]
@@ -283,6 +293,7 @@ __global__ __launch_bounds__(256, 2) void conv_tail_wino_kernel(TailWinoArgs k) 
         }
     }
 
+    if constexpr (O3) __syncthreads();      // every wave is done with the input patch, which t2 overlays
     // ---- phase 2: bias + ReLU; t2 lands in LDS as the A operand of the 1x1 (behind the input patch, which other waves
     // may still be reading): channel half wn, swizzled 128-byte rows like every operand image
     {
@@ -317,7 +328,7 @@ __global__ __launch_bounds__(256, 2) void conv_tail_wino_kernel(TailWinoArgs k) 
     // of HBM time for 4.9 GB -- and what separates it from them is that a CU's two workgroups overlap their matrix
     // and memory phases only by chance; staggering their start changed nothing, and without the raised priority of
     // the MFMA blocks the GEMM phase of one workgroup starves behind the other's epilogue (14 -> 24 us).
-    float* wch = smem;
+    float* wch = smem + CS_OFF / 4;
     int a3_off[MID / 32][2], b3_off[KK3][2];
 #pragma unroll
     for (int kk = 0; kk < KK3; ++kk)
@@ -325,7 +336,7 @@ __global__ __launch_bounds__(256, 2) void conv_tail_wino_kernel(TailWinoArgs k) 
         for (int part = 0; part < 2; ++part) {
             const int pos = ((part * 4 + fh) ^ sw) * 16;
             if (kk < MID / 32) a3_off[kk][part] = A_OFF + kk * (BM * 128) + (wm * (BM / 2) + frow) * 128 + pos;
-            b3_off[kk][part] = kk * (64 * 128) + (wn * 32 + frow) * 128 + pos;
+            b3_off[kk][part] = CS_OFF + kk * (64 * 128) + (wn * 32 + frow) * 128 + pos;
         }
     constexpr int RL = SC ? 0 : E::GROUPS * E::PASSES * 2;        // residual loads per chunk and lane
     const int nch = c.Cout / 64;
@@ -374,8 +385,8 @@ __global__ __launch_bounds__(256, 2) void conv_tail_wino_kernel(TailWinoArgs k) 
                 }
         }
         // (the epilogue's own first barrier separates the last weight read from the staging writes)
-        if constexpr (SC) split_epilogue16_rows<BM, BN, false>(c, smem, rows, ch, wave, lane, acc3);
-        else split_epilogue16_rows<BM, BN, true>(c, smem, rows, ch, wave, lane, acc3, res);
+        if constexpr (SC) split_epilogue16_rows<BM, BN, false>(c, wch, rows, ch, wave, lane, acc3);
+        else split_epilogue16_rows<BM, BN, true>(c, wch, rows, ch, wave, lane, acc3, res);
     }
 #endif
 }
